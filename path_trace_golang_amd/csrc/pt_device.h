@@ -1,0 +1,95 @@
+// pt_device.h -- device-side scene layout shared by the host set-up code and the
+// gfx950 kernels of libptcore.
+//
+// HBM layout (all per context, per device):
+//   DevObj  objs[nobj]     80 B each   world after sceneToWorld (objects.go:225-269), file order
+//   DevMat  mats[nmat+1]  104 B each   materials after convertMaterial (materials.go:28-55);
+//                                      slot nmat is the zero material of a missing id
+//   double  L[3][njobs]                per-job sample radiance of the current spp chunk (SoA)
+//   double  acc[3][nslots]             per-pixel-slot running sum over samples (SoA)
+//   uint8   tiles[ntiles][32][32][4]   resolved RGBA8, tile-major
+// A "slot" is one pixel position inside an owned 32x32 tile (renderer.go:132): tile lt,
+// 8x8 sub-block sb (row-major 4x4 inside the tile), pixel p (row-major 8x8):
+//   slot = (lt*16 + sb)*64 + p.
+// A "job" is one (slot, sample) pair of the current chunk of S samples:
+//   job  = ((lt*16 + sb)*S + (s - s0))*64 + p
+// so 64 consecutive jobs are one sample of one 8x8 block (coherent primary rays,
+// coalesced L traffic) and a wave that claims a job range stays inside one block.
+#pragma once
+
+#include <stdint.h>
+
+namespace ptd {
+
+enum { KIND_SPHERE = 0, KIND_PLANE = 1, KIND_BOX = 2 };
+enum { MAT_LAMBERT = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_EMISSIVE = 3, MAT_MIRROR = 4 };
+
+struct alignas(16) DevObj {
+    double a[3];       // sphere centre | plane point | box min
+    double b[3];       // -             | plane normal | box max
+    double radius;     // sphere
+    double radius_sq;  // radius*radius (objects.go:46), same product computed once on the host
+    double inv_radius; // 1.0/radius (objects.go:70)
+    int32_t kind;      // KIND_* in the low byte; bit 8 set when the material is dielectric
+    int32_t mat;       // index into mats[]
+};
+static_assert(sizeof(DevObj) == 80, "DevObj layout");
+
+struct alignas(8) DevMat {
+    double albedo[3];
+    double rough;
+    double ior;
+    double emit[3];
+    double absorption[3];
+    int32_t typ;
+    int32_t absorbs;   // absorption.x > 0 || .y > 0 || .z > 0 (renderer.go:360)
+    double rough_sq;   // rough*rough (materials.go:121)
+};
+static_assert(sizeof(DevMat) == 104, "DevMat layout");
+
+struct DevCamera {     // camera.go:9-17 after newCamera (camera.go:19-58)
+    double origin[3];
+    double lower_left[3];
+    double horizontal[3];
+    double vertical[3];
+    double u[3];
+    double v[3];
+    double lens_radius;
+};
+
+struct DevSky {
+    int32_t kind;      // PT_SKY_*
+    int32_t pad;
+    double c0[3];      // gradient: horizon; solid: colour; background: background
+    double c1[3];      // gradient: zenith
+};
+
+struct DevFrame {
+    int32_t width, height;
+    int32_t max_depth;
+    int32_t nobj;
+    int32_t nmat;        // materials incl. the zero material
+    int32_t ntx, nty;    // 32x32 tiles of the frame
+    int32_t shard_index, shard_count;
+    int32_t nlocal;      // tiles owned by this shard
+    uint32_t s0;         // first sample index of the chunk
+    uint32_t S;          // samples per pixel in the chunk
+    uint32_t njobs;      // nlocal*16*S*64
+    uint32_t claim;      // jobs a wave claims per queue pop (multiple of 64)
+    uint64_t seed_key;   // ptm::seed_key(seed)
+    double inv_width;    // 1/(W-1)  renderer.go:95
+    double inv_height;   // 1/(H-1)  renderer.go:96
+    double height_m1;    // H-1      renderer.go:98
+};
+
+struct TraceBuffers {
+    const DevObj *objs;
+    const DevMat *mats;
+    double *L;            // [3][njobs]
+    uint32_t *job_seg;    // [njobs] or null (PT_FLAG_PIXEL_STATS)
+    uint32_t *job_draw;   // [njobs] or null
+    unsigned int *queue;  // job queue head
+    unsigned long long *counters;  // [4]: segments, exit_scans, draws, samples
+};
+
+}  // namespace ptd

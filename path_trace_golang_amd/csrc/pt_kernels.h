@@ -1,0 +1,655 @@
+// pt_kernels.h -- gfx950 kernels of libptcore (included by ptcore.hip only).
+//
+//   trace_kernel    persistent waves; every lane owns one path at a time and pulls the
+//                   next (pixel, sample) job from a wave-level cursor that is refilled
+//                   from one global queue (ballot + mbcnt prefix rank).  Ray generation
+//                   (camera.go:60-74, renderer.go:181-184), the closest-hit scan over the
+//                   world (renderer.go:297-302; objects.go:37-222), shading
+//                   (materials.go:74-224), the dielectric exit search (renderer.go:316-371)
+//                   and Russian roulette (renderer.go:375-393) run in one loop whose
+//                   scan section is executed by all 64 lanes together: the exit search
+//                   of a glass hit is just that lane's next trip through the same scan.
+//                   The world is read with scalar loads (wave-uniform index) for the
+//                   scan and from an LDS copy for the per-lane winner look-up.
+//   resolve_kernel  per pixel slot, adds the chunk's sample radiances IN SAMPLE ORDER
+//                   to the running sum (renderer.go:186), and on request finishes the
+//                   pixel: 1/spp, sqrt gamma, *255.999, clamp, truncate (renderer.go:190-221).
+//   untile_kernel   tile-major -> row-major frame.
+//
+// FP64 throughout; built with -ffp-contract=off so every product and sum rounds
+// exactly as the reference's Go code does on amd64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pt_device.h"
+#include "pt_math.h"
+
+namespace ptk {
+
+using namespace ptd;
+
+#define PT_WAVE 64
+#define PT_BLOCK 256
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Outward normal of object `o` at surface point p (objects.go:70-73 sphere, :252 plane,
+// :186-217 box nearest face with strict '<' in the order -x,+x,-y,+y,-z,+z).
+template <typename ObjRef>
+__device__ __forceinline__ void outward_normal(const ObjRef &o, int kind, double px, double py, double pz, double &nx,
+                                               double &ny, double &nz) {
+    if (kind == KIND_SPHERE) {
+        nx = (px - o.a[0]) * o.inv_radius;
+        ny = (py - o.a[1]) * o.inv_radius;
+        nz = (pz - o.a[2]) * o.inv_radius;
+    } else if (kind == KIND_PLANE) {
+        nx = o.b[0];
+        ny = o.b[1];
+        nz = o.b[2];
+    } else {
+        double dxMin = px - o.a[0], dxMax = o.b[0] - px;
+        double dyMin = py - o.a[1], dyMax = o.b[1] - py;
+        double dzMin = pz - o.a[2], dzMax = o.b[2] - pz;
+        double minDist = dxMin;
+        nx = -1; ny = 0; nz = 0;
+        if (dxMax < minDist) { minDist = dxMax; nx = 1; ny = 0; nz = 0; }
+        if (dyMin < minDist) { minDist = dyMin; nx = 0; ny = -1; nz = 0; }
+        if (dyMax < minDist) { minDist = dyMax; nx = 0; ny = 1; nz = 0; }
+        if (dzMin < minDist) { minDist = dzMin; nx = 0; ny = 0; nz = -1; }
+        if (dzMax < minDist) { nx = 0; ny = 0; nz = 1; }
+    }
+}
+
+// reflectVec, math.go:39-46
+__device__ __forceinline__ void reflect_vec(double vx, double vy, double vz, double nx, double ny, double nz, double &rx,
+                                            double &ry, double &rz) {
+    double dot = vx * nx + vy * ny + vz * nz;
+    rx = vx - nx * 2 * dot;
+    ry = vy - ny * 2 * dot;
+    rz = vz - nz * 2 * dot;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const DevCamera cam, const DevSky sky,
+                                                           const TraceBuffers B) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    DevObj *s_obj = reinterpret_cast<DevObj *>(smem);
+    DevMat *s_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
+    {
+        // stage the world in LDS: the winner look-up after the scan is per lane
+        const uint64_t *g0 = reinterpret_cast<const uint64_t *>(B.objs);
+        uint64_t *l0 = reinterpret_cast<uint64_t *>(s_obj);
+        const int n0 = F.nobj * (int)(sizeof(DevObj) / 8);
+        for (int i = threadIdx.x; i < n0; i += PT_BLOCK) l0[i] = g0[i];
+        const uint64_t *g1 = reinterpret_cast<const uint64_t *>(B.mats);
+        uint64_t *l1 = reinterpret_cast<uint64_t *>(s_mat);
+        const int n1 = F.nmat * (int)(sizeof(DevMat) / 8);
+        for (int i = threadIdx.x; i < n1; i += PT_BLOCK) l1[i] = g1[i];
+    }
+    __syncthreads();
+
+    // The world is immutable for the whole launch: read it through the constant address
+    // space so the wave-uniform scan index turns into scalar (SGPR) loads.
+    typedef const DevObj __attribute__((address_space(4))) *ConstObjPtr;
+    const ConstObjPtr g_obj = (ConstObjPtr)(B.objs);
+    const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
+
+    // per-lane path state
+    bool active = false;
+    int mode = 0;  // 0: closest-hit scan, 1: dielectric exit search
+    int depth = 0;
+    int exit_mat = 0;
+    uint32_t job = 0;
+    uint64_t rs = 0;
+    double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+    double Tx = 1, Ty = 1, Tz = 1;
+    uint32_t c_seg = 0, c_exit = 0, c_draw = 0, c_samples = 0;
+    uint32_t j_seg = 0, j_draw = 0;
+
+    // wave-uniform job cursor
+    uint32_t cur = 0, end = 0;
+    bool exhausted = false;
+
+#define PT_DRAW(var)                 \
+    double var = ptm::stream_next(rs); \
+    c_draw++;                        \
+    if (STATS) j_draw++;
+
+    for (;;) {
+        // ------------------------------------------------------------ regeneration
+        const uint64_t need = __ballot(!active);
+        if (need != 0) {
+            if (cur >= end && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(B.queue, F.claim);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= F.njobs) {
+                    exhausted = true;
+                } else {
+                    cur = base;
+                    end = (F.njobs - base < F.claim) ? F.njobs : base + F.claim;
+                }
+            }
+            const uint32_t avail = end - cur;
+            const uint32_t rank = lane_rank(need);
+            const bool take = !active && rank < avail;
+            const uint32_t nneed = (uint32_t)__popcll(need);
+            const uint32_t myjob = cur + rank;
+            cur += nneed < avail ? nneed : avail;
+
+            if (take) {
+                // job -> (tile, sub-block, sample, pixel)
+                const uint32_t p = myjob & 63u;
+                const uint32_t q = myjob >> 6;
+                const uint32_t blk = q / F.S;
+                const uint32_t sl = q - blk * F.S;
+                const uint32_t lt = blk >> 4, sb = blk & 15u;
+                const uint32_t t = (uint32_t)F.shard_index + lt * (uint32_t)F.shard_count;
+                const uint32_t ty = t / (uint32_t)F.ntx, tx = t - ty * (uint32_t)F.ntx;
+                const uint32_t x = tx * 32u + (sb & 3u) * 8u + (p & 7u);
+                const uint32_t y = ty * 32u + (sb >> 2) * 8u + (p >> 3);
+                if (x < (uint32_t)F.width && y < (uint32_t)F.height) {
+                    job = myjob;
+                    active = true;
+                    mode = 0;
+                    depth = F.max_depth;
+                    Tx = 1; Ty = 1; Tz = 1;
+                    c_samples++;
+                    if (STATS) { j_seg = 0; j_draw = 0; }
+                    const uint64_t pixel = (uint64_t)y * (uint64_t)(uint32_t)F.width + (uint64_t)x;
+                    rs = ptm::stream_init(F.seed_key, pixel, (uint64_t)(F.s0 + sl));
+                    // renderer.go:182-183: u first, then v
+                    PT_DRAW(xi_u)
+                    PT_DRAW(xi_v)
+                    const double u = ((double)x + xi_u) * F.inv_width;
+                    const double vv = ((F.height_m1 - (double)y) + xi_v) * F.inv_height;
+                    // camera.getRay, camera.go:60-74
+                    const double tx_ = cam.lower_left[0] + cam.horizontal[0] * u;
+                    const double ty_ = cam.lower_left[1] + cam.horizontal[1] * u;
+                    const double tz_ = cam.lower_left[2] + cam.horizontal[2] * u;
+                    const double ax = tx_ + cam.vertical[0] * vv;
+                    const double ay = ty_ + cam.vertical[1] * vv;
+                    const double az = tz_ + cam.vertical[2] * vv;
+                    if (cam.lens_radius > 0) {
+                        double rx, ry, rz;
+                        for (;;) {  // randomInUnitSphere, math.go:74-84
+                            PT_DRAW(d0)
+                            PT_DRAW(d1)
+                            PT_DRAW(d2)
+                            rx = d0 * 2 - 1;
+                            ry = d1 * 2 - 1;
+                            rz = d2 * 2 - 1;
+                            const double lenSq = rx * rx + ry * ry + rz * rz;
+                            if (lenSq >= 1.0) continue;
+                            break;
+                        }
+                        rx = rx * cam.lens_radius;
+                        ry = ry * cam.lens_radius;
+                        const double offx = cam.u[0] * rx + cam.v[0] * ry;
+                        const double offy = cam.u[1] * rx + cam.v[1] * ry;
+                        const double offz = cam.u[2] * rx + cam.v[2] * ry;
+                        ox = cam.origin[0] + offx;
+                        oy = cam.origin[1] + offy;
+                        oz = cam.origin[2] + offz;
+                        dx = (ax - cam.origin[0]) - offx;
+                        dy = (ay - cam.origin[1]) - offy;
+                        dz = (az - cam.origin[2]) - offz;
+                    } else {
+                        ox = cam.origin[0];
+                        oy = cam.origin[1];
+                        oz = cam.origin[2];
+                        dx = ax - cam.origin[0];
+                        dy = ay - cam.origin[1];
+                        dz = az - cam.origin[2];
+                    }
+                }
+            }
+            if (__ballot(active) == 0) break;  // queue drained and every lane idle
+        }
+
+        bool finished = false;
+        double termx = 0, termy = 0, termz = 0;
+
+        if (active) {
+            // -------------------------------------------------------- scan
+            const double tmin = mode ? 0.0001 : 0.001;  // renderer.go:322 / :292
+            double tmax = ptm::max_float64();
+            int best = -1;
+            const double a = dx * dx + dy * dy + dz * dz;  // objects.go:43, same for every sphere
+            const double ivx = 1 / dx, ivy = 1 / dy, ivz = 1 / dz;  // objects.go:149,154,159
+
+            for (int i = 0; i < F.nobj; i++) {
+                const auto &o = g_obj[i];
+                const int kind = o.kind & 0xff;
+                const bool diel = (o.kind & 0x100) != 0;
+                if (mode != 0 && !diel) continue;  // only glass can end an exit search (renderer.go:333)
+                bool valid = false;
+                double t = 0;
+                if (kind == KIND_SPHERE) {  // objects.go:37-61
+                    const double ocx = ox - o.a[0], ocy = oy - o.a[1], ocz = oz - o.a[2];
+                    const double halfB = ocx * dx + ocy * dy + ocz * dz;
+                    const double ocLenSq = ocx * ocx + ocy * ocy + ocz * ocz;
+                    const double c = ocLenSq - o.radius_sq;
+                    const double disc = halfB * halfB - a * c;
+                    if (!(disc < 0)) {
+                        const double sq = ptm::f_sqrt(disc);
+                        double root = (-halfB - sq) / a;
+                        valid = true;
+                        if (root < tmin || root > tmax) {
+                            root = (-halfB + sq) / a;
+                            if (root < tmin || root > tmax) valid = false;
+                        }
+                        t = root;
+                    }
+                } else if (kind == KIND_BOX) {  // objects.go:141-179
+                    double t0 = tmin, t1 = tmax;
+                    double tn = (o.a[0] - ox) * ivx, tf = (o.b[0] - ox) * ivx;
+                    if (ivx < 0) { const double s = tn; tn = tf; tf = s; }
+                    if (tn > t0) t0 = tn;
+                    if (tf < t1) t1 = tf;
+                    tn = (o.a[1] - oy) * ivy; tf = (o.b[1] - oy) * ivy;
+                    if (ivy < 0) { const double s = tn; tn = tf; tf = s; }
+                    if (tn > t0) t0 = tn;
+                    if (tf < t1) t1 = tf;
+                    tn = (o.a[2] - oz) * ivz; tf = (o.b[2] - oz) * ivz;
+                    if (ivz < 0) { const double s = tn; tn = tf; tf = s; }
+                    if (tn > t0) t0 = tn;
+                    if (tf < t1) t1 = tf;
+                    // t0 only grows and t1 only shrinks, so the per-axis early return of
+                    // objects.go:176 equals this single test after the third axis
+                    valid = !(t1 <= t0);
+                    t = t0;
+                } else {  // plane, objects.go:98-112
+                    const double denom = o.b[0] * dx + o.b[1] * dy + o.b[2] * dz;
+                    if (!(ptm::f_abs(denom) < 1e-6)) {
+                        t = ((o.a[0] - ox) * o.b[0] + (o.a[1] - oy) * o.b[1] + (o.a[2] - oz) * o.b[2]) / denom;
+                        valid = !(t < tmin || t > tmax);
+                    }
+                }
+                if (valid) {
+                    if (mode == 0) {
+                        best = i;
+                        tmax = t;
+                    } else {
+                        // renderer.go:331-347: back face of glass, strictly nearer, sane distance
+                        const double px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;
+                        double nx, ny, nz;
+                        outward_normal(o, kind, px, py, pz, nx, ny, nz);
+                        const bool ff = (dx * nx + dy * ny + dz * nz) < 0;
+                        if (!ff && t < tmax) {
+                            const double ex = px - ox, ey = py - oy, ez = pz - oz;
+                            const double distSq = ex * ex + ey * ey + ez * ez;
+                            if (distSq > 1e-8 && distSq < 1000.0) {
+                                best = i;
+                                tmax = t;
+                            }
+                        }
+                    }
+                }
+            }
+
+            // -------------------------------------------------------- shade
+            bool do_rr = false;
+            double attx = 1, atty = 1, attz = 1;
+            if (mode == 0) {
+                c_seg++;
+                if (STATS) j_seg++;
+                if (best < 0) {
+                    // sky closure, renderer.go:56-92
+                    finished = true;
+                    if (sky.kind == 1) {
+                        const double dirLen = ptm::f_sqrt(dx * dx + dy * dy + dz * dz);
+                        if (dirLen == 0) {
+                            termx = sky.c0[0]; termy = sky.c0[1]; termz = sky.c0[2];
+                        } else {
+                            double tt = (dy / dirLen + 1.0) * 0.5;
+                            if (tt < 0) tt = 0;
+                            if (tt > 1) tt = 1;
+                            termx = sky.c0[0] * (1 - tt) + sky.c1[0] * tt;
+                            termy = sky.c0[1] * (1 - tt) + sky.c1[1] * tt;
+                            termz = sky.c0[2] * (1 - tt) + sky.c1[2] * tt;
+                        }
+                    } else {
+                        termx = sky.c0[0]; termy = sky.c0[1]; termz = sky.c0[2];
+                    }
+                } else {
+                    const DevObj &o = s_obj[best];
+                    const int kind = o.kind & 0xff;
+                    const double px = ox + dx * tmax, py = oy + dy * tmax, pz = oz + dz * tmax;
+                    double nx, ny, nz;
+                    outward_normal(o, kind, px, py, pz, nx, ny, nz);
+                    const bool ff = (dx * nx + dy * ny + dz * nz) < 0;
+                    if (!ff) { nx = -nx; ny = -ny; nz = -nz; }
+                    const int mi = o.mat;
+                    const DevMat &m = s_mat[mi];
+                    const int typ = m.typ;
+                    if (typ == MAT_EMISSIVE) {  // materials.go:67-72, :202-203
+                        finished = true;
+                        termx = m.emit[0]; termy = m.emit[1]; termz = m.emit[2];
+                    } else {
+                        // unit direction for the specular kinds (materials.go:102-109, :175-182, :207-214)
+                        double ux = 0, uy = 0, uz = 0, rfx = 0, rfy = 0, rfz = 0;
+                        bool zero_dir = false;
+                        if (typ != MAT_LAMBERT) {
+                            const double dirLen = ptm::f_sqrt(dx * dx + dy * dy + dz * dz);
+                            if (dirLen == 0) {
+                                zero_dir = true;
+                            } else {
+                                const double invLen = 1.0 / dirLen;
+                                ux = dx * invLen; uy = dy * invLen; uz = dz * invLen;
+                                reflect_vec(ux, uy, uz, nx, ny, nz, rfx, rfy, rfz);
+                            }
+                        }
+                        if (zero_dir) {
+                            finished = true;  // scatter fails -> emitted (0)
+                        } else {
+                            double ndx = rfx, ndy = rfy, ndz = rfz;  // mirror / smooth metal / reflecting glass
+                            const bool cosine = (typ == MAT_LAMBERT) || (typ == MAT_METAL && m.rough > 1e-6);
+                            if (cosine) {
+                                // randomCosineDirection, math.go:94-131, about the normal (lambert)
+                                // or about the mirror direction (rough metal, materials.go:119)
+                                const double wx = (typ == MAT_LAMBERT) ? nx : rfx;
+                                const double wy = (typ == MAT_LAMBERT) ? ny : rfy;
+                                const double wz = (typ == MAT_LAMBERT) ? nz : rfz;
+                                PT_DRAW(r1)
+                                PT_DRAW(r2)
+                                const double phi = 6.283185307179586 * r1;
+                                const double cosTheta = ptm::f_sqrt(r2);
+                                const double sinTheta = ptm::f_sqrt(1.0 - r2);
+                                const bool xmajor = ptm::f_abs(wx) > 0.9;
+                                const double hx = xmajor ? 0.0 : 1.0, hy = xmajor ? 1.0 : 0.0, hz = 0.0;
+                                // vVec = unit(w x h), uVec = vVec x w
+                                double cx = wy * hz - wz * hy;
+                                double cy = wz * hx - wx * hz;
+                                double cz = wx * hy - wy * hx;
+                                const double cl = ptm::f_sqrt(cx * cx + cy * cy + cz * cz);
+                                if (cl != 0) {
+                                    const double inv = 1.0 / cl;
+                                    cx = cx * inv; cy = cy * inv; cz = cz * inv;
+                                }
+                                const double bx = cy * wz - cz * wy;
+                                const double by = cz * wx - cx * wz;
+                                const double bz = cx * wy - cy * wx;
+                                double sn, cs;
+                                ptm::sincos_pos(phi, &sn, &cs);
+                                const double lx = sinTheta * cs, ly = sinTheta * sn, lz = cosTheta;
+                                double sx = lx * bx + ly * cx + lz * wx;
+                                double sy = lx * by + ly * cy + lz * wy;
+                                double sz = lx * bz + ly * cz + lz * wz;
+                                if (typ == MAT_LAMBERT) {
+                                    if (m.rough > 1e-6) {  // materials.go:84-91
+                                        double qx, qy, qz;
+                                        for (;;) {
+                                            PT_DRAW(d0)
+                                            PT_DRAW(d1)
+                                            PT_DRAW(d2)
+                                            qx = d0 * 2 - 1; qy = d1 * 2 - 1; qz = d2 * 2 - 1;
+                                            if (qx * qx + qy * qy + qz * qz >= 1.0) continue;
+                                            break;
+                                        }
+                                        sx += qx * m.rough * 0.1;
+                                        sy += qy * m.rough * 0.1;
+                                        sz += qz * m.rough * 0.1;
+                                        const double l = ptm::f_sqrt(sx * sx + sy * sy + sz * sz);
+                                        if (l != 0) {
+                                            const double inv = 1.0 / l;
+                                            sx = sx * inv; sy = sy * inv; sz = sz * inv;
+                                        }
+                                    }
+                                    ndx = sx; ndy = sy; ndz = sz;
+                                } else {
+                                    // materials.go:121-148
+                                    const double alpha = m.rough_sq;
+                                    double mx = rfx * (1.0 - alpha) + sx * alpha;
+                                    double my = rfy * (1.0 - alpha) + sy * alpha;
+                                    double mz = rfz * (1.0 - alpha) + sz * alpha;
+                                    const double lenSq = mx * mx + my * my + mz * mz;
+                                    if (lenSq < 1e-8) {
+                                        mx = rfx; my = rfy; mz = rfz;
+                                    } else {
+                                        const double inv = 1.0 / ptm::f_sqrt(lenSq);
+                                        mx *= inv; my *= inv; mz *= inv;
+                                    }
+                                    const double dot = mx * nx + my * ny + mz * nz;
+                                    if (dot <= 0) { mx = rfx; my = rfy; mz = rfz; }
+                                    ndx = mx; ndy = my; ndz = mz;
+                                }
+                            }
+                            if (typ == MAT_DIELECTRIC) {  // materials.go:162-200
+                                const double ratio = ff ? 1.0 / m.ior : m.ior;
+                                const double cosTheta = ptm::go_min(-(ux * nx + uy * ny + uz * nz), 1.0);
+                                const double sinTheta = ptm::f_sqrt(1.0 - cosTheta * cosTheta);
+                                const bool cannot = ratio * sinTheta > 1.0;
+                                double r0 = (1 - ratio) / (1 + ratio);
+                                r0 = r0 * r0;
+                                const double reflectProb = r0 + (1 - r0) * ptm::go_pow5(1 - cosTheta);
+                                bool reflects = cannot;
+                                if (!cannot) {  // Go's || short-circuit: the draw happens only here
+                                    PT_DRAW(xi)
+                                    reflects = reflectProb > xi;
+                                }
+                                if (!reflects) {  // refractVec, math.go:48-64
+                                    const double ct = ptm::go_min(-ux * nx - uy * ny - uz * nz, 1.0);
+                                    double qx = ux + nx * ct, qy = uy + ny * ct, qz = uz + nz * ct;
+                                    qx *= ratio; qy *= ratio; qz *= ratio;
+                                    const double perpLenSq = qx * qx + qy * qy + qz * qz;
+                                    const double par = -ptm::f_sqrt(ptm::f_abs(1.0 - perpLenSq));
+                                    ndx = qx + nx * par; ndy = qy + ny * par; ndz = qz + nz * par;
+                                }
+                            } else {
+                                attx = m.albedo[0]; atty = m.albedo[1]; attz = m.albedo[2];
+                            }
+                            // scattered ray starts at the hit point (no offset)
+                            ox = px; oy = py; oz = pz;
+                            dx = ndx; dy = ndy; dz = ndz;
+                            if (typ == MAT_DIELECTRIC && ff) {
+                                mode = 1;  // renderer.go:316-319: find the way out before roulette
+                                exit_mat = mi;
+                                c_exit++;
+                            } else {
+                                do_rr = true;
+                            }
+                        }
+                    }
+                }
+            } else {
+                // exit search done (renderer.go:352-370); the hit point of the entry is the ray origin
+                if (best >= 0) {
+                    const double px = ox + dx * tmax, py = oy + dy * tmax, pz = oz + dz * tmax;
+                    const double ex = px - ox, ey = py - oy, ez = pz - oz;
+                    const double distance = ptm::f_sqrt(ex * ex + ey * ey + ez * ez);
+                    const DevMat &m = s_mat[exit_mat];
+                    if (m.absorbs) {
+                        attx = ptm::go_exp(-m.absorption[0] * distance);
+                        atty = ptm::go_exp(-m.absorption[1] * distance);
+                        attz = ptm::go_exp(-m.absorption[2] * distance);
+                    }
+                    ox = px; oy = py; oz = pz;
+                }
+                mode = 0;
+                do_rr = true;
+            }
+
+            // ------------------------------------------------------------ roulette + advance
+            if (do_rr) {
+                if (depth <= 3) {  // renderer.go:375-393
+                    const double maxAtt = ptm::go_max(attx, ptm::go_max(atty, attz));
+                    if (maxAtt < 1e-6) {
+                        finished = true;
+                    } else {
+                        const double rrProb = ptm::go_min(maxAtt, 0.95);
+                        PT_DRAW(xi)
+                        if (xi > rrProb) {
+                            finished = true;
+                        } else {
+                            attx /= rrProb; atty /= rrProb; attz /= rrProb;
+                        }
+                    }
+                }
+                if (!finished) {
+                    Tx *= attx; Ty *= atty; Tz *= attz;
+                    depth--;
+                    if (depth <= 0) finished = true;  // renderer.go:287-289 contributes zero
+                }
+            }
+
+            if (finished) {
+                B.L[job] = Tx * termx;
+                B.L[(size_t)F.njobs + job] = Ty * termy;
+                B.L[2 * (size_t)F.njobs + job] = Tz * termz;
+                if (STATS) {
+                    B.job_seg[job] = j_seg;
+                    B.job_draw[job] = j_draw;
+                }
+                active = false;
+            }
+        }
+    }
+#undef PT_DRAW
+
+    // counters: one atomic per wave
+    const uint32_t w_seg = wave_sum(c_seg), w_exit = wave_sum(c_exit), w_draw = wave_sum(c_draw),
+                   w_samples = wave_sum(c_samples);
+    if (lane == 0) {
+        atomicAdd(&B.counters[0], (unsigned long long)w_seg);
+        atomicAdd(&B.counters[1], (unsigned long long)w_exit);
+        atomicAdd(&B.counters[2], (unsigned long long)w_draw);
+        atomicAdd(&B.counters[3], (unsigned long long)w_samples);
+    }
+}
+
+// uint8(v) of renderer.go:218-220 after the clamp of :200-217; NaN -> 0 as on amd64.
+__device__ __forceinline__ uint32_t quantise(double v) {
+    if (v < 0) v = 0;
+    else if (v > 255.999) v = 255.999;
+    if (v != v) return 0;
+    return (uint32_t)v;
+}
+
+struct ResolveArgs {
+    const double *L;         // [3][njobs]
+    const uint32_t *job_seg; // [njobs] or null
+    const uint32_t *job_draw;
+    double *acc;             // [3][nslots]
+    uint32_t *acc_seg;       // [nslots] or null
+    uint32_t *acc_draw;
+    uint8_t *tiles_rgba;     // [nlocal][32][32][4] or null (no finish)
+    double *tiles_accum;     // [nlocal][32][32][3] or null
+    uint32_t *tiles_seg;     // [nlocal][32][32] or null
+    uint32_t *tiles_draw;
+    uint32_t nslots;         // nlocal*1024
+    uint32_t njobs;
+    uint32_t S;
+    int32_t first;           // 1: the running sum starts at zero
+    int32_t finish;          // 1: write tiles_rgba / tiles_accum
+    int32_t have_chunk;      // 0: no chunk to add (pure finish, pt_read)
+    double inv_samples;      // 1/spp_done
+    int32_t width, height, ntx, shard_index, shard_count;
+};
+
+__global__ __launch_bounds__(PT_BLOCK) void resolve_kernel(const ResolveArgs R) {
+    const uint32_t slot = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (slot >= R.nslots) return;
+    const uint32_t blk = slot >> 6, p = slot & 63u;
+    const uint32_t lt = blk >> 4, sb = blk & 15u;
+    const uint32_t t = (uint32_t)R.shard_index + lt * (uint32_t)R.shard_count;
+    const uint32_t ty = t / (uint32_t)R.ntx, tx = t - ty * (uint32_t)R.ntx;
+    const uint32_t lx = (sb & 3u) * 8u + (p & 7u), ly = (sb >> 2) * 8u + (p >> 3);
+    const uint32_t x = tx * 32u + lx, y = ty * 32u + ly;
+    const bool inside = x < (uint32_t)R.width && y < (uint32_t)R.height;
+
+    double cx = 0, cy = 0, cz = 0;
+    uint32_t nseg = 0, ndraw = 0;
+    if (inside) {
+        if (!R.first) {
+            cx = R.acc[slot];
+            cy = R.acc[(size_t)R.nslots + slot];
+            cz = R.acc[2 * (size_t)R.nslots + slot];
+            if (R.acc_seg) { nseg = R.acc_seg[slot]; ndraw = R.acc_draw[slot]; }
+        }
+        if (R.have_chunk) {
+            const size_t base = (size_t)blk * R.S * 64u + p;
+            for (uint32_t s = 0; s < R.S; s++) {  // col = col.add(sample), renderer.go:186, in sample order
+                const size_t j = base + (size_t)s * 64u;
+                cx += R.L[j];
+                cy += R.L[(size_t)R.njobs + j];
+                cz += R.L[2 * (size_t)R.njobs + j];
+                if (R.job_seg) { nseg += R.job_seg[j]; ndraw += R.job_draw[j]; }
+            }
+            R.acc[slot] = cx;
+            R.acc[(size_t)R.nslots + slot] = cy;
+            R.acc[2 * (size_t)R.nslots + slot] = cz;
+            if (R.acc_seg) { R.acc_seg[slot] = nseg; R.acc_draw[slot] = ndraw; }
+        }
+    }
+    if (R.finish) {
+        const size_t pix = (size_t)lt * 1024u + ly * 32u + lx;
+        if (R.tiles_rgba) {
+            uint32_t packed = 0;
+            if (inside) {
+                // renderer.go:190-221
+                const double r = ptm::f_sqrt(cx * R.inv_samples) * 255.999;
+                const double g = ptm::f_sqrt(cy * R.inv_samples) * 255.999;
+                const double b = ptm::f_sqrt(cz * R.inv_samples) * 255.999;
+                packed = quantise(r) | (quantise(g) << 8) | (quantise(b) << 16) | (255u << 24);
+            }
+            reinterpret_cast<uint32_t *>(R.tiles_rgba)[pix] = packed;
+        }
+        if (R.tiles_accum) {
+            R.tiles_accum[3 * pix] = inside ? cx : 0.0;
+            R.tiles_accum[3 * pix + 1] = inside ? cy : 0.0;
+            R.tiles_accum[3 * pix + 2] = inside ? cz : 0.0;
+        }
+        if (R.tiles_seg) {
+            R.tiles_seg[pix] = inside ? nseg : 0u;
+            R.tiles_draw[pix] = inside ? ndraw : 0u;
+        }
+    }
+}
+
+struct UntileArgs {
+    const uint8_t *tiles_rgba;   // concatenated per shard: shard k holds its tiles in local order
+    const double *tiles_accum;   // or null
+    const uint32_t *tiles_u32a;  // optional per-pixel u32 planes in tile order (stats)
+    const uint32_t *tiles_u32b;
+    uint8_t *rgba;               // row-major frame, `stride` bytes per row (or null)
+    double *accum;               // width*height*3 (or null)
+    uint32_t *u32a, *u32b;       // width*height (or null)
+    int32_t width, height, ntx, nty, stride, shard_count;
+};
+
+__global__ __launch_bounds__(PT_BLOCK) void untile_kernel(const UntileArgs U) {
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u);
+    const uint32_t y = blockIdx.y * 32u + (threadIdx.x >> 5) + blockIdx.z * 8u;
+    if (x >= (uint32_t)U.width || y >= (uint32_t)U.height) return;
+    const uint32_t tx = x >> 5, ty = y >> 5;
+    const uint32_t t = ty * (uint32_t)U.ntx + tx;
+    const uint32_t ntiles = (uint32_t)U.ntx * (uint32_t)U.nty;
+    const uint32_t k = t % (uint32_t)U.shard_count, lt = t / (uint32_t)U.shard_count;
+    // tiles owned by shards 0..k-1
+    const uint32_t q = ntiles / (uint32_t)U.shard_count, r = ntiles % (uint32_t)U.shard_count;
+    const uint32_t before = k * q + (k < r ? k : r);
+    const size_t pix = ((size_t)before + lt) * 1024u + (y & 31u) * 32u + (x & 31u);
+    if (U.rgba)
+        *reinterpret_cast<uint32_t *>(U.rgba + (size_t)y * (size_t)U.stride + (size_t)x * 4u) =
+            reinterpret_cast<const uint32_t *>(U.tiles_rgba)[pix];
+    const size_t o = (size_t)y * (size_t)U.width + x;
+    if (U.accum) {
+        U.accum[3 * o] = U.tiles_accum[3 * pix];
+        U.accum[3 * o + 1] = U.tiles_accum[3 * pix + 1];
+        U.accum[3 * o + 2] = U.tiles_accum[3 * pix + 2];
+    }
+    if (U.u32a) U.u32a[o] = U.tiles_u32a[pix];
+    if (U.u32b) U.u32b[o] = U.tiles_u32b[pix];
+}
+
+}  // namespace ptk

@@ -1,0 +1,872 @@
+// ptcore.hip -- libptcore.so: C ABI (include/ptcore.h) over the gfx950 kernels.
+//
+// Host responsibilities, all restating the set-up half of the reference CPU engine:
+//   * convertMaterial      internal/engine/materials.go:28-55
+//   * sceneToWorld         internal/engine/objects.go:225-269
+//   * newCamera            internal/engine/camera.go:19-58
+//   * sky closure select   internal/engine/renderer.go:56-92
+//   * frame constants      internal/engine/renderer.go:95-98
+//   * 32x32 tile grid      internal/engine/renderer.go:132-157 (here: the multi-GPU shard unit)
+// then per chunk of samples: reset queue -> trace_kernel -> resolve_kernel.
+// There is no CPU rendering path in this library: without a HIP device every entry
+// point fails with PT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptcore.h"
+#include "pt_device.h"
+#include "pt_kernels.h"
+#include "pt_math.h"
+
+using namespace ptd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+// One device's share of a frame.
+struct Device {
+    int ordinal = 0;
+    int num_cu = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // own_stream or the caller's
+    DevBuf<DevObj> objs;
+    DevBuf<DevMat> mats;
+    DevBuf<double> L;
+    DevBuf<uint32_t> job_seg, job_draw;
+    DevBuf<double> acc;
+    DevBuf<uint32_t> acc_seg, acc_draw;
+    DevBuf<uint8_t> tiles_rgba;
+    DevBuf<double> tiles_accum;
+    DevBuf<uint32_t> tiles_seg, tiles_draw;
+    DevBuf<unsigned int> queue;
+    DevBuf<unsigned long long> counters;
+    std::vector<EventPair> ev_trace, ev_resolve;
+    size_t n_trace = 0, n_resolve = 0;
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    bool first_recorded = false;
+    // frame state
+    pt_shard shard{0, 1};
+    int32_t nlocal = 0;
+    uint32_t nslots = 0;
+    bool acc_started = false;
+    int blocks_per_cu = 0;
+};
+
+struct Frame {
+    bool open = false;
+    pt_config cfg{};
+    DevFrame F{};
+    DevCamera cam{};
+    DevSky sky{};
+    int32_t nobj = 0, nmat = 0;
+    int32_t ntx = 0, nty = 0;
+    int32_t done_spp = 0;
+    uint32_t chunk = 0;
+    bool stats_on = false;
+    std::chrono::steady_clock::time_point t0;
+};
+
+}  // namespace
+
+struct pt_ctx {
+    std::vector<Device> devs;
+    Frame frame;
+    // device-0 gather / frame buffers for the host-memory entry points
+    DevBuf<uint8_t> g_tiles_rgba;
+    DevBuf<double> g_tiles_accum;
+    DevBuf<uint32_t> g_tiles_seg, g_tiles_draw;
+    DevBuf<uint8_t> f_rgba;
+    DevBuf<double> f_accum;
+    DevBuf<uint32_t> f_seg, f_draw;
+    size_t l_budget_bytes = (size_t)2 << 30;
+    uint32_t claim = 256;
+    int max_blocks_per_cu = 8;
+};
+
+namespace {
+
+// ---------------------------------------------------------------- scene conversion
+
+double clampd(double x, double lo, double hi) {  // materials.go:57-65
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+
+DevMat convert_material(const pt_material &m) {  // materials.go:28-55
+    DevMat r;
+    std::memset(&r, 0, sizeof r);
+    switch (m.type) {
+        case PT_MAT_METAL: {
+            double rough = m.rough;
+            if (m.smoothness > 0) rough = 1.0 - clampd(m.smoothness, 0, 1);
+            r.typ = MAT_METAL;
+            for (int i = 0; i < 3; i++) r.albedo[i] = m.albedo[i];
+            r.rough = clampd(rough, 0, 1);
+            break;
+        }
+        case PT_MAT_DIELECTRIC: {
+            double ior = m.ior;
+            if (ior == 0) ior = 1.5;
+            r.typ = MAT_DIELECTRIC;
+            for (int i = 0; i < 3; i++) { r.albedo[i] = m.albedo[i]; r.absorption[i] = m.absorption[i]; }
+            r.ior = ior;
+            break;
+        }
+        case PT_MAT_EMISSIVE:
+            r.typ = MAT_EMISSIVE;
+            for (int i = 0; i < 3; i++) r.emit[i] = m.emit[i] * m.power;
+            break;
+        case PT_MAT_MIRROR:
+            r.typ = MAT_MIRROR;
+            for (int i = 0; i < 3; i++) r.albedo[i] = m.albedo[i];
+            break;
+        default:
+            r.typ = MAT_LAMBERT;
+            for (int i = 0; i < 3; i++) r.albedo[i] = m.albedo[i];
+            r.rough = clampd(m.rough, 0, 1);
+            break;
+    }
+    r.absorbs = (r.absorption[0] > 0 || r.absorption[1] > 0 || r.absorption[2] > 0) ? 1 : 0;
+    r.rough_sq = r.rough * r.rough;
+    return r;
+}
+
+// objects.go:225-269; materials are converted once and indexed (the zero material
+// of a missing id is slot num_materials)
+void scene_to_world(const pt_scene &sc, std::vector<DevObj> &world, std::vector<DevMat> &mats) {
+    mats.clear();
+    for (int i = 0; i < sc.num_materials; i++) mats.push_back(convert_material(sc.materials[i]));
+    DevMat zero;
+    std::memset(&zero, 0, sizeof zero);
+    mats.push_back(zero);
+    world.clear();
+    for (int i = 0; i < sc.num_objects; i++) {
+        const pt_object &o = sc.objects[i];
+        DevObj d;
+        std::memset(&d, 0, sizeof d);
+        d.mat = (o.material >= 0 && o.material < sc.num_materials) ? o.material : sc.num_materials;
+        int kind;
+        switch (o.type) {
+            case PT_OBJ_SPHERE:
+            case PT_OBJ_SPHERE_LIGHT:
+                kind = KIND_SPHERE;
+                for (int k = 0; k < 3; k++) d.a[k] = o.position[k];
+                d.radius = o.size[0];
+                d.radius_sq = d.radius * d.radius;
+                d.inv_radius = 1.0 / d.radius;
+                break;
+            case PT_OBJ_PLANE:
+                kind = KIND_PLANE;
+                for (int k = 0; k < 3; k++) d.a[k] = o.position[k];
+                d.b[0] = 0; d.b[1] = 1; d.b[2] = 0;
+                break;
+            case PT_OBJ_BOX:
+                kind = KIND_BOX;
+                for (int k = 0; k < 3; k++) {
+                    d.a[k] = o.position[k] - o.size[k] * 0.5;
+                    d.b[k] = o.position[k] + o.size[k] * 0.5;
+                }
+                break;
+            default:
+                continue;  // unknown types are skipped
+        }
+        d.kind = kind | (mats[(size_t)d.mat].typ == MAT_DIELECTRIC ? 0x100 : 0);
+        world.push_back(d);
+    }
+}
+
+struct H3 {
+    double x, y, z;
+};
+H3 h3(const double *p) { return H3{p[0], p[1], p[2]}; }
+H3 sub(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+H3 mul(H3 a, double t) { return H3{a.x * t, a.y * t, a.z * t}; }
+H3 divs(H3 a, double t) { double inv = 1.0 / t; return H3{a.x * inv, a.y * inv, a.z * inv}; }
+double dot(H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+H3 cross(H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+double length(H3 a) { return ptm::f_sqrt(dot(a, a)); }
+H3 unit(H3 a) {
+    double l = length(a);
+    if (l == 0) return a;
+    return divs(a, l);
+}
+void put(double *d, H3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+DevCamera new_camera(const pt_camera &c, int width, int height) {  // camera.go:19-58
+    DevCamera cam;
+    double aspect = (double)width / (double)height;
+    if (c.aspect_ratio != 0) aspect = c.aspect_ratio;
+    const double theta = c.fov * 3.141592653589793 / 180;
+    const double h = ptm::go_tan(theta / 2);
+    const double viewportHeight = 2.0 * h;
+    const double viewportWidth = aspect * viewportHeight;
+    const H3 origin = h3(c.position), target = h3(c.target), up = h3(c.up);
+    const H3 w = unit(sub(origin, target));
+    const H3 u = unit(cross(up, w));
+    const H3 v = cross(w, u);
+    double focusDist = c.focus_dist;
+    if (focusDist == 0) focusDist = length(sub(origin, target));
+    const H3 horizontal = mul(u, viewportWidth * focusDist);
+    const H3 vertical = mul(v, viewportHeight * focusDist);
+    const H3 llc = sub(sub(sub(origin, divs(horizontal, 2)), divs(vertical, 2)), mul(w, focusDist));
+    put(cam.origin, origin);
+    put(cam.lower_left, llc);
+    put(cam.horizontal, horizontal);
+    put(cam.vertical, vertical);
+    put(cam.u, u);
+    put(cam.v, v);
+    cam.lens_radius = c.aperture / 2;
+    return cam;
+}
+
+DevSky make_sky(const pt_sky &s) {  // renderer.go:56-92
+    DevSky d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = s.kind == PT_SKY_GRADIENT ? 1 : (s.kind == PT_SKY_SOLID ? 2 : 0);
+    const double *c0 = d.kind == 1 ? s.horizon : (d.kind == 2 ? s.color : s.background);
+    for (int i = 0; i < 3; i++) { d.c0[i] = c0[i]; d.c1[i] = s.zenith[i]; }
+    return d;
+}
+
+int32_t tiles_of_shard(int32_t ntiles, const pt_shard &sh) {
+    if (sh.index >= ntiles) return 0;
+    return (ntiles - sh.index + sh.count - 1) / sh.count;
+}
+
+int32_t validate(const pt_scene *scene, const pt_config *cfg) {
+    if (!scene || !cfg) return fail(PT_ERR_INVALID, "null scene or config");
+    if (cfg->width <= 0 || cfg->height <= 0) return fail(PT_ERR_INVALID, "width and height must be positive");
+    if (cfg->samples_per_px < 0) return fail(PT_ERR_INVALID, "samples_per_px must be >= 0");
+    if ((int64_t)cfg->width * cfg->height > (int64_t)1 << 28) return fail(PT_ERR_INVALID, "frame too large");
+    if (scene->num_materials < 0 || scene->num_objects < 0) return fail(PT_ERR_INVALID, "negative scene counts");
+    if (scene->num_materials > 0 && !scene->materials) return fail(PT_ERR_INVALID, "materials is null");
+    if (scene->num_objects > 0 && !scene->objects) return fail(PT_ERR_INVALID, "objects is null");
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------- per-device frame
+
+int32_t dev_events(Device &d, std::vector<EventPair> &v, size_t need) {
+    while (v.size() < need) {
+        EventPair e;
+        HIP_TRY(hipEventCreate(&e.a));
+        HIP_TRY(hipEventCreate(&e.b));
+        v.push_back(e);
+    }
+    (void)d;
+    return PT_OK;
+}
+
+int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, const std::vector<DevMat> &mats,
+                  const pt_shard &shard, hipStream_t stream) {
+    Frame &fr = ctx->frame;
+    HIP_TRY(hipSetDevice(d.ordinal));
+    d.stream = stream ? stream : d.own_stream;
+    d.shard = shard;
+    d.nlocal = tiles_of_shard(fr.ntx * fr.nty, shard);
+    d.nslots = (uint32_t)d.nlocal * 1024u;
+    d.acc_started = false;
+    d.n_trace = d.n_resolve = 0;
+    d.first_recorded = false;
+    HIP_TRY(d.objs.reserve(std::max<size_t>(1, world.size())));
+    HIP_TRY(d.mats.reserve(mats.size()));
+    if (!world.empty())
+        HIP_TRY(hipMemcpyAsync(d.objs.p, world.data(), world.size() * sizeof(DevObj), hipMemcpyHostToDevice, d.stream));
+    HIP_TRY(hipMemcpyAsync(d.mats.p, mats.data(), mats.size() * sizeof(DevMat), hipMemcpyHostToDevice, d.stream));
+    // the copies above read pageable host vectors that die with the caller's scope
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    HIP_TRY(d.queue.reserve(1));
+    HIP_TRY(d.counters.reserve(4));
+    HIP_TRY(hipMemsetAsync(d.counters.p, 0, 4 * sizeof(unsigned long long), d.stream));
+    const size_t ns = std::max<uint32_t>(1, d.nslots);
+    HIP_TRY(d.acc.reserve(3 * ns));
+    if (fr.stats_on) {
+        HIP_TRY(d.acc_seg.reserve(ns));
+        HIP_TRY(d.acc_draw.reserve(ns));
+    }
+    const size_t njobs_max = (size_t)ns * fr.chunk;
+    HIP_TRY(d.L.reserve(3 * njobs_max));
+    if (fr.stats_on) {
+        HIP_TRY(d.job_seg.reserve(njobs_max));
+        HIP_TRY(d.job_draw.reserve(njobs_max));
+    }
+    if (!d.ev_first) {
+        HIP_TRY(hipEventCreate(&d.ev_first));
+        HIP_TRY(hipEventCreate(&d.ev_last));
+    }
+    // occupancy of the trace kernel for this scene's LDS footprint
+    const size_t lds = (size_t)fr.nobj * sizeof(DevObj) + (size_t)fr.nmat * sizeof(DevMat);
+    if (lds > 160 * 1024) return fail(PT_ERR_INVALID, "scene does not fit the 160 KiB LDS of a CU");
+    int nb = 0;
+    if (fr.stats_on)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<true>, PT_BLOCK, lds));
+    else
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<false>, PT_BLOCK, lds));
+    d.blocks_per_cu = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
+    return PT_OK;
+}
+
+// Adds samples [s0, s0+S) to this device's running sums.
+int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
+    Frame &fr = ctx->frame;
+    if (d.nlocal == 0 || S == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(d.ordinal));
+    DevFrame F = fr.F;
+    F.shard_index = d.shard.index;
+    F.shard_count = d.shard.count;
+    F.nlocal = d.nlocal;
+    F.s0 = s0;
+    F.S = S;
+    F.njobs = d.nslots * S;
+    F.claim = ctx->claim;
+    TraceBuffers B;
+    B.objs = d.objs.p;
+    B.mats = d.mats.p;
+    B.L = d.L.p;
+    B.job_seg = fr.stats_on ? d.job_seg.p : nullptr;
+    B.job_draw = fr.stats_on ? d.job_draw.p : nullptr;
+    B.queue = d.queue.p;
+    B.counters = d.counters.p;
+
+    if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + 1)) return rc;
+    if (int32_t rc = dev_events(d, d.ev_resolve, d.n_resolve + 1)) return rc;
+    if (!d.first_recorded) {
+        HIP_TRY(hipEventRecord(d.ev_first, d.stream));
+        d.first_recorded = true;
+    }
+    if (fr.cfg.max_depth <= 0) {
+        // rayColorOpt returns black at depth <= 0 (renderer.go:287-289): nothing to trace
+        HIP_TRY(hipMemsetAsync(d.L.p, 0, 3 * (size_t)F.njobs * sizeof(double), d.stream));
+        if (fr.stats_on) {
+            HIP_TRY(hipMemsetAsync(d.job_seg.p, 0, (size_t)F.njobs * sizeof(uint32_t), d.stream));
+            HIP_TRY(hipMemsetAsync(d.job_draw.p, 0, (size_t)F.njobs * sizeof(uint32_t), d.stream));
+        }
+    } else {
+        HIP_TRY(hipMemsetAsync(d.queue.p, 0, sizeof(unsigned int), d.stream));
+        const size_t lds = (size_t)fr.nobj * sizeof(DevObj) + (size_t)fr.nmat * sizeof(DevMat);
+        const uint32_t waves_needed = (F.njobs + 63u) / 64u;
+        uint32_t grid = (uint32_t)(d.num_cu * d.blocks_per_cu);
+        grid = std::max(1u, std::min(grid, (waves_needed + 3u) / 4u));
+        EventPair &e = d.ev_trace[d.n_trace++];
+        HIP_TRY(hipEventRecord(e.a, d.stream));
+        if (fr.stats_on)
+            hipLaunchKernelGGL(ptk::trace_kernel<true>, dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
+        else
+            hipLaunchKernelGGL(ptk::trace_kernel<false>, dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e.b, d.stream));
+    }
+    ptk::ResolveArgs R;
+    std::memset(&R, 0, sizeof R);
+    R.L = d.L.p;
+    R.job_seg = B.job_seg;
+    R.job_draw = B.job_draw;
+    R.acc = d.acc.p;
+    R.acc_seg = fr.stats_on ? d.acc_seg.p : nullptr;
+    R.acc_draw = fr.stats_on ? d.acc_draw.p : nullptr;
+    R.nslots = d.nslots;
+    R.njobs = F.njobs;
+    R.S = S;
+    R.first = d.acc_started ? 0 : 1;
+    R.finish = 0;
+    R.have_chunk = 1;
+    R.inv_samples = 0;
+    R.width = fr.cfg.width;
+    R.height = fr.cfg.height;
+    R.ntx = fr.ntx;
+    R.shard_index = d.shard.index;
+    R.shard_count = d.shard.count;
+    EventPair &e = d.ev_resolve[d.n_resolve++];
+    HIP_TRY(hipEventRecord(e.a, d.stream));
+    hipLaunchKernelGGL(ptk::resolve_kernel, dim3((d.nslots + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, d.stream, R);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e.b, d.stream));
+    d.acc_started = true;
+    return PT_OK;
+}
+
+// Writes the current estimate of this device's tiles (normalised by spp_done).
+int32_t dev_finish(pt_ctx *ctx, Device &d, int32_t spp_done, uint8_t *tiles_rgba, double *tiles_accum,
+                   uint32_t *tiles_seg, uint32_t *tiles_draw) {
+    Frame &fr = ctx->frame;
+    if (d.nlocal == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(d.ordinal));
+    ptk::ResolveArgs R;
+    std::memset(&R, 0, sizeof R);
+    R.acc = d.acc.p;
+    R.acc_seg = fr.stats_on ? d.acc_seg.p : nullptr;
+    R.acc_draw = fr.stats_on ? d.acc_draw.p : nullptr;
+    R.tiles_rgba = tiles_rgba;
+    R.tiles_accum = tiles_accum;
+    R.tiles_seg = fr.stats_on ? tiles_seg : nullptr;
+    R.tiles_draw = fr.stats_on ? tiles_draw : nullptr;
+    R.nslots = d.nslots;
+    R.first = d.acc_started ? 0 : 1;
+    R.finish = 1;
+    R.have_chunk = 0;
+    R.inv_samples = 1.0 / (double)spp_done;  // renderer.go:97
+    R.width = fr.cfg.width;
+    R.height = fr.cfg.height;
+    R.ntx = fr.ntx;
+    R.shard_index = d.shard.index;
+    R.shard_count = d.shard.count;
+    if (int32_t rc = dev_events(d, d.ev_resolve, d.n_resolve + 1)) return rc;
+    EventPair &e = d.ev_resolve[d.n_resolve++];
+    HIP_TRY(hipEventRecord(e.a, d.stream));
+    hipLaunchKernelGGL(ptk::resolve_kernel, dim3((d.nslots + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, d.stream, R);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e.b, d.stream));
+    HIP_TRY(hipEventRecord(d.ev_last, d.stream));
+    return PT_OK;
+}
+
+int32_t dev_collect(Device &d, pt_stats *st, int slot) {
+    HIP_TRY(hipSetDevice(d.ordinal));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    if (d.nlocal == 0) return PT_OK;
+    unsigned long long c[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(c, d.counters.p, sizeof c, hipMemcpyDeviceToHost));
+    st->segments += c[0];
+    st->exit_scans += c[1];
+    st->draws += c[2];
+    st->samples += c[3];
+    double tr = 0, rs = 0;
+    for (size_t i = 0; i < d.n_trace; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d.ev_trace[i].a, d.ev_trace[i].b));
+        tr += ms;
+    }
+    for (size_t i = 0; i < d.n_resolve; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d.ev_resolve[i].a, d.ev_resolve[i].b));
+        rs += ms;
+    }
+    float span = 0;
+    if (d.first_recorded) HIP_TRY(hipEventElapsedTime(&span, d.ev_first, d.ev_last));
+    st->trace_ms = std::max(st->trace_ms, tr);
+    st->resolve_ms = std::max(st->resolve_ms, rs);
+    st->device_ms = std::max(st->device_ms, (double)span);
+    st->trace_launches += (int32_t)d.n_trace;
+    st->resolve_launches += (int32_t)d.n_resolve;
+    if (slot < 8) st->per_device_ms[slot] = span;
+    return PT_OK;
+}
+
+int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, std::vector<DevObj> &world,
+                   std::vector<DevMat> &mats, uint32_t max_slots) {
+    Frame &fr = ctx->frame;
+    fr = Frame();
+    fr.cfg = *cfg;
+    scene_to_world(*scene, world, mats);
+    fr.nobj = (int32_t)world.size();
+    fr.nmat = (int32_t)mats.size();
+    fr.cam = new_camera(scene->camera, cfg->width, cfg->height);
+    fr.sky = make_sky(scene->sky);
+    fr.ntx = (cfg->width + 31) / 32;
+    fr.nty = (cfg->height + 31) / 32;
+    fr.stats_on = (cfg->flags & PT_FLAG_PIXEL_STATS) != 0;
+    DevFrame &F = fr.F;
+    std::memset(&F, 0, sizeof F);
+    F.width = cfg->width;
+    F.height = cfg->height;
+    F.max_depth = cfg->max_depth;
+    F.nobj = fr.nobj;
+    F.nmat = fr.nmat;
+    F.ntx = fr.ntx;
+    F.nty = fr.nty;
+    F.seed_key = ptm::seed_key(cfg->seed);
+    F.inv_width = 1.0 / (double)(cfg->width - 1);
+    F.inv_height = 1.0 / (double)(cfg->height - 1);
+    F.height_m1 = (double)(cfg->height - 1);
+    // chunk of samples per pass: bounded by the L budget and by 2^31 jobs
+    uint32_t chunk = cfg->spp_chunk > 0 ? (uint32_t)cfg->spp_chunk : 0;
+    const uint32_t slots = std::max(1u, max_slots);
+    if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * 24));
+    chunk = std::min<uint32_t>(chunk, (uint32_t)std::max(1, cfg->samples_per_px));
+    chunk = std::min<uint32_t>(chunk, std::max(1u, 0x7fffffffu / slots));
+    fr.chunk = chunk;
+    fr.done_spp = 0;
+    fr.t0 = std::chrono::steady_clock::now();
+    fr.open = true;
+    return PT_OK;
+}
+
+void fill_stats_common(pt_ctx *ctx, pt_stats *st) {
+    Frame &fr = ctx->frame;
+    st->spp_chunk = (int32_t)fr.chunk;
+    st->num_devices = (int32_t)ctx->devs.size();
+    st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - fr.t0).count();
+}
+
+}  // namespace
+
+// ==================================================================== C ABI
+
+extern "C" {
+
+int32_t pt_abi_version(void) { return PT_ABI_VERSION; }
+
+const char *pt_last_error(void) { return g_last_error.c_str(); }
+
+int32_t pt_device_count(int32_t *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = (e == hipSuccess) ? n : 0;
+    if (e != hipSuccess || n <= 0) return fail(PT_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
+    if (!out) return fail(PT_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (ndev <= 0 || ndev > 64) return fail(PT_ERR_INVALID, "ndev must be in 1..64");
+    int32_t n = 0;
+    if (int32_t rc = pt_device_count(&n)) return rc;
+    pt_ctx *ctx = new pt_ctx();
+    if (const char *e = std::getenv("PTCORE_L_BUDGET_MB")) {
+        long mb = std::atol(e);
+        if (mb > 0) ctx->l_budget_bytes = (size_t)mb << 20;
+    }
+    if (const char *e = std::getenv("PTCORE_CLAIM")) {
+        long c = std::atol(e);
+        if (c >= 64 && c % 64 == 0) ctx->claim = (uint32_t)c;
+    }
+    if (const char *e = std::getenv("PTCORE_BLOCKS_PER_CU")) {
+        long c = std::atol(e);
+        if (c >= 1 && c <= 8) ctx->max_blocks_per_cu = (int)c;
+    }
+    ctx->devs.resize((size_t)ndev);
+    for (int i = 0; i < ndev; i++) {
+        Device &d = ctx->devs[(size_t)i];
+        d.ordinal = devices ? devices[i] : i;
+        if (d.ordinal < 0 || d.ordinal >= n) {
+            pt_destroy(ctx);
+            return fail(PT_ERR_INVALID, "device ordinal out of range");
+        }
+        hipError_t e = hipSetDevice(d.ordinal);
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, d.ordinal);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.own_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            pt_destroy(ctx);
+            return fail(PT_ERR_HIP, std::string("device init: ") + hipGetErrorString(e));
+        }
+        d.num_cu = prop.multiProcessorCount;
+        d.stream = d.own_stream;
+    }
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx *ctx) {
+    if (!ctx) return;
+    for (Device &d : ctx->devs) {
+        if (hipSetDevice(d.ordinal) != hipSuccess) continue;
+        if (d.own_stream) (void)hipStreamSynchronize(d.own_stream);
+        d.objs.release(); d.mats.release(); d.L.release(); d.job_seg.release(); d.job_draw.release();
+        d.acc.release(); d.acc_seg.release(); d.acc_draw.release(); d.tiles_rgba.release();
+        d.tiles_accum.release(); d.tiles_seg.release(); d.tiles_draw.release(); d.queue.release();
+        d.counters.release();
+        for (EventPair &e : d.ev_trace) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (EventPair &e : d.ev_resolve) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        if (d.ev_first) (void)hipEventDestroy(d.ev_first);
+        if (d.ev_last) (void)hipEventDestroy(d.ev_last);
+        if (d.own_stream) (void)hipStreamDestroy(d.own_stream);
+    }
+    if (!ctx->devs.empty() && hipSetDevice(ctx->devs[0].ordinal) == hipSuccess) {
+        ctx->g_tiles_rgba.release(); ctx->g_tiles_accum.release(); ctx->g_tiles_seg.release();
+        ctx->g_tiles_draw.release(); ctx->f_rgba.release(); ctx->f_accum.release(); ctx->f_seg.release();
+        ctx->f_draw.release();
+    }
+    delete ctx;
+}
+
+int32_t pt_shard_tiles(int32_t width, int32_t height, const pt_shard *shard, int32_t *ntiles_local, int32_t *ntiles_x,
+                       int32_t *ntiles_y) {
+    if (width <= 0 || height <= 0) return fail(PT_ERR_INVALID, "width and height must be positive");
+    pt_shard sh = shard ? *shard : pt_shard{0, 1};
+    if (sh.count <= 0 || sh.index < 0 || sh.index >= sh.count) return fail(PT_ERR_INVALID, "bad shard");
+    const int32_t ntx = (width + 31) / 32, nty = (height + 31) / 32;
+    if (ntiles_x) *ntiles_x = ntx;
+    if (ntiles_y) *ntiles_y = nty;
+    if (ntiles_local) *ntiles_local = tiles_of_shard(ntx * nty, sh);
+    return PT_OK;
+}
+
+int32_t pt_begin(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg) {
+    if (!ctx) return fail(PT_ERR_INVALID, "ctx is null");
+    if (int32_t rc = validate(scene, cfg)) return rc;
+    if (ctx->frame.open) return fail(PT_ERR_STATE, "pt_begin: a frame is already open");
+    const int32_t ndev = (int32_t)ctx->devs.size();
+    const int32_t ntiles = ((cfg->width + 31) / 32) * ((cfg->height + 31) / 32);
+    std::vector<DevObj> world;
+    std::vector<DevMat> mats;
+    const uint32_t max_slots = (uint32_t)tiles_of_shard(ntiles, pt_shard{0, ndev}) * 1024u;
+    if (int32_t rc = frame_open(ctx, scene, cfg, world, mats, max_slots)) return rc;
+    for (int32_t i = 0; i < ndev; i++) {
+        if (int32_t rc = dev_begin(ctx, ctx->devs[(size_t)i], world, mats, pt_shard{i, ndev}, nullptr)) {
+            ctx->frame.open = false;
+            return rc;
+        }
+    }
+    return PT_OK;
+}
+
+int32_t pt_step(pt_ctx *ctx, int32_t nspp, int32_t *done_spp) {
+    if (!ctx || !ctx->frame.open) return fail(PT_ERR_STATE, "pt_step without pt_begin");
+    Frame &fr = ctx->frame;
+    int32_t left = fr.cfg.samples_per_px - fr.done_spp;
+    int32_t todo = std::max(0, std::min(nspp, left));
+    while (todo > 0) {
+        const uint32_t S = std::min<uint32_t>((uint32_t)todo, fr.chunk);
+        for (Device &d : ctx->devs)
+            if (int32_t rc = dev_step(ctx, d, (uint32_t)fr.done_spp, S)) return rc;
+        fr.done_spp += (int32_t)S;
+        todo -= (int32_t)S;
+    }
+    for (Device &d : ctx->devs) {
+        HIP_TRY(hipSetDevice(d.ordinal));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+    }
+    if (done_spp) *done_spp = fr.done_spp;
+    return PT_OK;
+}
+
+// gathers every device's tiles on device 0, untiles, copies to host
+static int32_t read_frame(pt_ctx *ctx, uint8_t *rgba, int32_t stride, double *accum, uint32_t *nseg, uint32_t *ndraw) {
+    Frame &fr = ctx->frame;
+    const int32_t W = fr.cfg.width, H = fr.cfg.height;
+    if (rgba && stride < W * 4) return fail(PT_ERR_INVALID, "stride smaller than 4*width");
+    const int32_t ndev = (int32_t)ctx->devs.size();
+    const size_t ntiles = (size_t)fr.ntx * (size_t)fr.nty;
+    const bool want_stats = fr.stats_on && (nseg || ndraw);
+    Device &d0 = ctx->devs[0];
+    HIP_TRY(hipSetDevice(d0.ordinal));
+    HIP_TRY(ctx->g_tiles_rgba.reserve(ntiles * 4096));
+    if (accum) HIP_TRY(ctx->g_tiles_accum.reserve(ntiles * 1024 * 3));
+    if (want_stats) {
+        HIP_TRY(ctx->g_tiles_seg.reserve(ntiles * 1024));
+        HIP_TRY(ctx->g_tiles_draw.reserve(ntiles * 1024));
+    }
+    const int32_t spp_done = fr.done_spp;
+    size_t before = 0;
+    for (int32_t i = 0; i < ndev; i++) {
+        Device &d = ctx->devs[(size_t)i];
+        if (d.nlocal == 0) continue;
+        const size_t nt = (size_t)d.nlocal;
+        if (i == 0) {
+            // device 0 resolves straight into the gather buffer
+            if (int32_t rc = dev_finish(ctx, d, spp_done, ctx->g_tiles_rgba.p + before * 4096,
+                                        accum ? ctx->g_tiles_accum.p + before * 3072 : nullptr,
+                                        want_stats ? ctx->g_tiles_seg.p + before * 1024 : nullptr,
+                                        want_stats ? ctx->g_tiles_draw.p + before * 1024 : nullptr))
+                return rc;
+        } else {
+            HIP_TRY(hipSetDevice(d.ordinal));
+            HIP_TRY(d.tiles_rgba.reserve(nt * 4096));
+            if (accum) HIP_TRY(d.tiles_accum.reserve(nt * 3072));
+            if (want_stats) {
+                HIP_TRY(d.tiles_seg.reserve(nt * 1024));
+                HIP_TRY(d.tiles_draw.reserve(nt * 1024));
+            }
+            if (int32_t rc = dev_finish(ctx, d, spp_done, d.tiles_rgba.p, accum ? d.tiles_accum.p : nullptr,
+                                        want_stats ? d.tiles_seg.p : nullptr, want_stats ? d.tiles_draw.p : nullptr))
+                return rc;
+            // gather over xGMI: peer DMA into device 0's buffer, ordered on the source stream
+            HIP_TRY(hipMemcpyPeerAsync(ctx->g_tiles_rgba.p + before * 4096, d0.ordinal, d.tiles_rgba.p, d.ordinal,
+                                       nt * 4096, d.stream));
+            if (accum)
+                HIP_TRY(hipMemcpyPeerAsync(ctx->g_tiles_accum.p + before * 3072, d0.ordinal, d.tiles_accum.p, d.ordinal,
+                                           nt * 3072 * sizeof(double), d.stream));
+            if (want_stats) {
+                HIP_TRY(hipMemcpyPeerAsync(ctx->g_tiles_seg.p + before * 1024, d0.ordinal, d.tiles_seg.p, d.ordinal,
+                                           nt * 1024 * sizeof(uint32_t), d.stream));
+                HIP_TRY(hipMemcpyPeerAsync(ctx->g_tiles_draw.p + before * 1024, d0.ordinal, d.tiles_draw.p, d.ordinal,
+                                           nt * 1024 * sizeof(uint32_t), d.stream));
+            }
+        }
+        before += nt;
+    }
+    for (int32_t i = 1; i < ndev; i++) {
+        HIP_TRY(hipSetDevice(ctx->devs[(size_t)i].ordinal));
+        HIP_TRY(hipStreamSynchronize(ctx->devs[(size_t)i].stream));
+    }
+    HIP_TRY(hipSetDevice(d0.ordinal));
+    HIP_TRY(ctx->f_rgba.reserve((size_t)W * H * 4));
+    if (accum) HIP_TRY(ctx->f_accum.reserve((size_t)W * H * 3));
+    if (want_stats) {
+        HIP_TRY(ctx->f_seg.reserve((size_t)W * H));
+        HIP_TRY(ctx->f_draw.reserve((size_t)W * H));
+    }
+    ptk::UntileArgs U;
+    std::memset(&U, 0, sizeof U);
+    U.tiles_rgba = ctx->g_tiles_rgba.p;
+    U.tiles_accum = accum ? ctx->g_tiles_accum.p : nullptr;
+    U.tiles_u32a = want_stats ? ctx->g_tiles_seg.p : nullptr;
+    U.tiles_u32b = want_stats ? ctx->g_tiles_draw.p : nullptr;
+    U.rgba = ctx->f_rgba.p;
+    U.accum = accum ? ctx->f_accum.p : nullptr;
+    U.u32a = want_stats ? ctx->f_seg.p : nullptr;
+    U.u32b = want_stats ? ctx->f_draw.p : nullptr;
+    U.width = W; U.height = H; U.ntx = fr.ntx; U.nty = fr.nty; U.stride = W * 4; U.shard_count = ndev;
+    hipLaunchKernelGGL(ptk::untile_kernel, dim3((unsigned)fr.ntx, (unsigned)fr.nty, 4), dim3(PT_BLOCK), 0, d0.stream, U);
+    HIP_TRY(hipGetLastError());
+    if (rgba)
+        HIP_TRY(hipMemcpy2DAsync(rgba, (size_t)stride, ctx->f_rgba.p, (size_t)W * 4, (size_t)W * 4, (size_t)H,
+                                 hipMemcpyDeviceToHost, d0.stream));
+    if (accum)
+        HIP_TRY(hipMemcpyAsync(accum, ctx->f_accum.p, (size_t)W * H * 3 * sizeof(double), hipMemcpyDeviceToHost, d0.stream));
+    if (want_stats && nseg)
+        HIP_TRY(hipMemcpyAsync(nseg, ctx->f_seg.p, (size_t)W * H * sizeof(uint32_t), hipMemcpyDeviceToHost, d0.stream));
+    if (want_stats && ndraw)
+        HIP_TRY(hipMemcpyAsync(ndraw, ctx->f_draw.p, (size_t)W * H * sizeof(uint32_t), hipMemcpyDeviceToHost, d0.stream));
+    HIP_TRY(hipStreamSynchronize(d0.stream));
+    return PT_OK;
+}
+
+int32_t pt_read(pt_ctx *ctx, uint8_t *rgba, int32_t stride, double *accum) {
+    if (!ctx || !ctx->frame.open) return fail(PT_ERR_STATE, "pt_read without pt_begin");
+    return read_frame(ctx, rgba, stride, accum, nullptr, nullptr);
+}
+
+int32_t pt_end(pt_ctx *ctx, pt_stats *stats) {
+    if (!ctx || !ctx->frame.open) return fail(PT_ERR_STATE, "pt_end without pt_begin");
+    pt_stats st;
+    std::memset(&st, 0, sizeof st);
+    int32_t rc = PT_OK;
+    int slot = 0;
+    for (Device &d : ctx->devs) {
+        if (!d.first_recorded || d.nlocal == 0) { slot++; continue; }
+        // make sure ev_last exists even if pt_read was never called
+        if (hipSetDevice(d.ordinal) == hipSuccess) (void)hipEventRecord(d.ev_last, d.stream);
+        if (int32_t r = dev_collect(d, &st, slot)) rc = r;
+        slot++;
+    }
+    fill_stats_common(ctx, &st);
+    ctx->frame.open = false;
+    if (stats) *stats = st;
+    return rc;
+}
+
+int32_t pt_render(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uint8_t *rgba, int32_t stride, double *accum,
+                  uint32_t *nseg, uint32_t *ndraw, pt_stats *stats) {
+    if (!ctx) return fail(PT_ERR_INVALID, "ctx is null");
+    if ((nseg || ndraw) && cfg && !(cfg->flags & PT_FLAG_PIXEL_STATS))
+        return fail(PT_ERR_INVALID, "nseg/ndraw need PT_FLAG_PIXEL_STATS");
+    if (int32_t rc = pt_begin(ctx, scene, cfg)) return rc;
+    int32_t rc = pt_step(ctx, cfg->samples_per_px, nullptr);
+    if (rc == PT_OK) rc = read_frame(ctx, rgba, stride, accum, nseg, ndraw);
+    pt_stats st;
+    int32_t rc2 = pt_end(ctx, &st);
+    if (stats) *stats = st;
+    return rc != PT_OK ? rc : rc2;
+}
+
+int32_t pt_render_tiles_device(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, const pt_shard *shard,
+                               void *d_tiles_rgba, void *d_tiles_accum, void *stream, pt_stats *stats) {
+    if (!ctx) return fail(PT_ERR_INVALID, "ctx is null");
+    if (int32_t rc = validate(scene, cfg)) return rc;
+    if (ctx->frame.open) return fail(PT_ERR_STATE, "a frame is already open");
+    if (!d_tiles_rgba) return fail(PT_ERR_INVALID, "d_tiles_rgba is null");
+    pt_shard sh = shard ? *shard : pt_shard{0, 1};
+    if (sh.count <= 0 || sh.index < 0 || sh.index >= sh.count) return fail(PT_ERR_INVALID, "bad shard");
+    if (cfg->flags & PT_FLAG_PIXEL_STATS) return fail(PT_ERR_INVALID, "pixel stats are not available on the device entry point");
+    const int32_t ntiles = ((cfg->width + 31) / 32) * ((cfg->height + 31) / 32);
+    std::vector<DevObj> world;
+    std::vector<DevMat> mats;
+    const uint32_t slots = (uint32_t)tiles_of_shard(ntiles, sh) * 1024u;
+    if (int32_t rc = frame_open(ctx, scene, cfg, world, mats, slots)) return rc;
+    Frame &fr = ctx->frame;
+    Device &d = ctx->devs[0];
+    int32_t rc = dev_begin(ctx, d, world, mats, sh, static_cast<hipStream_t>(stream));
+    for (int32_t s = 0; rc == PT_OK && s < cfg->samples_per_px;) {
+        const uint32_t S = std::min<uint32_t>((uint32_t)(cfg->samples_per_px - s), fr.chunk);
+        rc = dev_step(ctx, d, (uint32_t)s, S);
+        s += (int32_t)S;
+    }
+    fr.done_spp = cfg->samples_per_px;
+    if (rc == PT_OK)
+        rc = dev_finish(ctx, d, cfg->samples_per_px, static_cast<uint8_t *>(d_tiles_rgba), static_cast<double *>(d_tiles_accum),
+                        nullptr, nullptr);
+    if (rc == PT_OK && stats) {
+        pt_stats st;
+        std::memset(&st, 0, sizeof st);
+        rc = dev_collect(d, &st, 0);
+        fill_stats_common(ctx, &st);
+        st.num_devices = 1;
+        *stats = st;
+    }
+    fr.open = false;
+    return rc;
+}
+
+int32_t pt_untile_device(pt_ctx *ctx, int32_t width, int32_t height, int32_t shard_count, const void *d_tiles_rgba,
+                         const void *d_tiles_accum, void *d_rgba, int32_t stride, void *d_accum, void *stream) {
+    if (!ctx) return fail(PT_ERR_INVALID, "ctx is null");
+    if (width <= 0 || height <= 0 || shard_count <= 0) return fail(PT_ERR_INVALID, "bad frame or shard count");
+    if (d_rgba && (stride < width * 4 || stride % 4 != 0)) return fail(PT_ERR_INVALID, "stride must be a multiple of 4 and >= 4*width");
+    if (d_rgba && !d_tiles_rgba) return fail(PT_ERR_INVALID, "d_tiles_rgba is null");
+    if (d_accum && !d_tiles_accum) return fail(PT_ERR_INVALID, "d_tiles_accum is null");
+    Device &d = ctx->devs[0];
+    HIP_TRY(hipSetDevice(d.ordinal));
+    ptk::UntileArgs U;
+    std::memset(&U, 0, sizeof U);
+    U.tiles_rgba = static_cast<const uint8_t *>(d_tiles_rgba);
+    U.tiles_accum = d_accum ? static_cast<const double *>(d_tiles_accum) : nullptr;
+    U.rgba = static_cast<uint8_t *>(d_rgba);
+    U.accum = static_cast<double *>(d_accum);
+    U.width = width; U.height = height;
+    U.ntx = (width + 31) / 32; U.nty = (height + 31) / 32;
+    U.stride = stride; U.shard_count = shard_count;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : d.own_stream;
+    hipLaunchKernelGGL(ptk::untile_kernel, dim3((unsigned)U.ntx, (unsigned)U.nty, 4), dim3(PT_BLOCK), 0, s, U);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+}  // extern "C"
