@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: path segments per second of the render loop on MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one whole frame of BASELINE config 4, the configuration the metric is
+quoted on: scenes/gpu_showcase.json at 1920x1080, 1024 spp, max depth 8 (synthetic in
+the sense that it is the scene file itself; there are no weights or datasets).  The
+frame is split over interleaved 32x32 tiles, one process per GPU; each rank renders
+its tiles through the C ABI (pt_render_tiles_device), the per-tile framebuffers are
+gathered on rank 0 over RCCL (torch.distributed "nccl" gather) and untiled there.  No
+collective touches the data path before that gather.
+
+value = millions of path segments (closest-hit queries = rays x bounces)
+summed over all ranks and steps / wall time (max over ranks).  Primary samples/s is
+reported beside it.  The 5 KB scene upload is inside the timed region; the output
+stays in HBM.
+
+roofline: the dominant kernel is ptk::trace_kernel.  It is FP64-VALU bound, not HBM
+bound (its path state lives in registers): "roofline" states its algorithmic HBM
+bytes honestly against the 8 TB/s peak (a tiny fraction by design) and
+"roofline_fp64" states the binding resource.  See DESIGN.md.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_NOFMA_TOPS = 39.3    # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one op per lane (no FMA contraction)
+
+
+def seg_flops(n_sphere: int, n_box: int, n_plane: int) -> float:
+    """Algorithmic FP64 ops per segment, SURVEY.md 8(d) / BASELINE.md 5."""
+    return 23.0 * n_sphere + 12.0 * n_box + 14.0 * n_plane + 150.0
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="gpu_showcase")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--spp-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=2, help="spp of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    import torch  # first: libptcore must resolve libamdhip64.so.7 to the copy torch already loaded
+    import torch.distributed as dist
+
+    from path_trace_golang_amd import capi, hip, scene
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                  % (args.gpus, args.gpus), file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X: torch.cuda.is_available() is False", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    capi.load()
+    L = capi.load()
+    ctx = capi.Context(devices=[local_rank])
+    sc = scene.load(os.path.join(ROOT, "scenes", args.scene + ".json"))
+    flat = hip.FlatScene(sc)
+    cfg = hip.pt_config(hip.RenderConfig(args.width, args.height, args.spp, args.depth, args.seed, args.spp_chunk, 0))
+    W, H = args.width, args.height
+
+    shard = capi.PtShard(rank, world)
+    ntl, ntx, nty = C.c_int32(), C.c_int32(), C.c_int32()
+    capi.check(L.pt_shard_tiles(W, H, C.byref(shard), C.byref(ntl), C.byref(ntx), C.byref(nty)))
+    s0 = capi.PtShard(0, world)
+    ntl_max = C.c_int32()
+    capi.check(L.pt_shard_tiles(W, H, C.byref(s0), C.byref(ntl_max), None, None))
+    stride_tiles = ntl_max.value
+
+    tiles = torch.zeros(stride_tiles * 4096, dtype=torch.uint8, device=dev)
+    gathered = None
+    frame = None
+    if rank == 0:
+        gathered = [torch.empty_like(tiles) for _ in range(world)] if world > 1 else None
+        frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        st = capi.PtStats()
+        capi.check(L.pt_render_tiles_device(ctx.handle, C.byref(flat.c), C.byref(cfg), C.byref(shard),
+                                            C.c_void_p(tiles.data_ptr()), None, C.c_void_p(stream.cuda_stream),
+                                            C.byref(st)))
+        if world > 1:
+            dist.gather(tiles, gathered, dst=0)
+        if rank == 0:
+            src = torch.cat(gathered) if world > 1 else tiles
+            capi.check(L.pt_untile_device(ctx.handle, W, H, world, stride_tiles, C.c_void_p(src.data_ptr()), None,
+                                          C.c_void_p(frame.data_ptr()), W * 4, None, C.c_void_p(stream.cuda_stream)))
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([float(sum(s.segments for s in stats)), float(sum(s.samples for s in stats)),
+                        float(sum(s.exit_scans for s in stats))], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    segments, samples, exits = (float(x) for x in tot.tolist())
+
+    out = None
+    if rank == 0:
+        steps = max(1, args.steps)
+        trace_ms = sum(s.trace_ms for s in stats)
+        n_launch = sum(s.trace_launches for s in stats)
+        resolve_ms = sum(s.resolve_ms for s in stats)
+        avg_launch_s = (trace_ms / max(1, n_launch)) * 1e-3
+        # algorithmic HBM bytes of one trace launch: 24 B of radiance per job + the world once per block
+        chunk = stats[0].spp_chunk if stats else 0
+        ntl_local = ntl.value
+        spp_per_launch = args.spp / max(1, (n_launch / steps))
+        jobs_per_launch = ntl_local * 1024.0 * spp_per_launch
+        alg_bytes = 24.0 * jobs_per_launch
+        achieved_gbs = alg_bytes / max(avg_launch_s, 1e-12) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("trace_kernel", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        objs = [o.type for o in sc.objects]
+        n_sph = sum(1 for t in objs if t in ("sphere", "sphere_light"))
+        n_box = sum(1 for t in objs if t == "box")
+        n_pl = sum(1 for t in objs if t == "plane")
+        fseg = seg_flops(n_sph, n_box, n_pl)
+        rank0_seg_per_s = sum(s.segments for s in stats) / max(trace_ms * 1e-3, 1e-12)
+        fp64_tops = rank0_seg_per_s * fseg / 1e12
+        out = {
+            "metric": "Msamples/s (rays x bounces/s) at %dx%dx%dspp" % (W, H, args.spp),
+            "value": segments / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "scenes/%s.json %dx%d, %d spp, max depth %d, seed %d (BASELINE config 4)"
+                                   % (args.scene, W, H, args.spp, args.depth, args.seed),
+                       "tiles": "32x32 interleaved over %d rank(s)" % world, "gather": "rccl" if world > 1 else "none",
+                       "spp_chunk": chunk},
+            "primary_msamples_per_s": samples / elapsed / 1e6,
+            "segments_per_sample": segments / max(samples, 1.0),
+            "exit_scans_per_segment": exits / max(segments, 1.0),
+            "pixel_rmse_vs_cpu_ref": None,
+            "roofline": {"bound": "hbm", "kernel": "ptk::trace_kernel<false>", "achieved": achieved_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic, "alg_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": n_launch / steps,
+                         "note": "register-resident paths: HBM carries only 24 B of radiance per sample; "
+                                 "the binding resource is FP64 VALU, see roofline_fp64"},
+            "roofline_fp64": {"bound": "fp64_valu", "achieved": fp64_tops, "peak": FP64_PEAK_NOFMA_TOPS,
+                              "unit": "Tflop/s (unfused)", "frac": fp64_tops / FP64_PEAK_NOFMA_TOPS,
+                              "alg_flops_per_segment": fseg,
+                              "trace_share_of_step": trace_ms / max(elapsed * 1e3, 1e-9),
+                              "resolve_ms_per_step": resolve_ms / steps},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import ora  # CPU restatement of the reference engine: the timed baseline only
+
+            osc = ora.Scene.load(os.path.join(ROOT, "scenes", args.scene + ".json"))
+            r = ora.render(osc, W, H, args.cpu_spp, args.depth, seed=args.seed, want=("rgba", "accum"))
+            cst = r["stats"]
+            out["cpu_baseline"] = {
+                "value": cst["segments"] / cst["seconds"] / 1e6, "unit": "Msamples/s", "cores": cst["workers"],
+                "kind": "port",
+                "sample": "same scene and frame size, %d of %d spp (%.1f s of CPU work on %d threads); C restatement "
+                          "of internal/engine (oracle/pt_oracle.c), the Go reference cannot be built here"
+                          % (args.cpu_spp, args.spp, cst["seconds"], cst["workers"]),
+                "primary_msamples_per_s": cst["samples"] / cst["seconds"] / 1e6,
+            }
+            out["gpu_over_cpu"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-12)
+            # parity spot check on the same sample: GPU at cpu_spp vs the oracle image
+            import numpy as np
+
+            img = np.zeros((H, W, 4), np.uint8)
+            acc = np.zeros((H, W, 3), np.float64)
+            hip.render(sc, hip.RenderConfig(W, H, args.cpu_spp, args.depth, args.seed), img, None, acc, ctx=ctx)
+            g = np.sqrt(np.clip(acc / args.cpu_spp, 0, 1))
+            o = np.sqrt(np.clip(r["accum"] / args.cpu_spp, 0, 1))
+            out["pixel_rmse_vs_cpu_ref"] = float(np.sqrt(np.mean((g - o) ** 2)))
+            out["rgba8_bytes_differing"] = int(np.count_nonzero(img != r["rgba"]))
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

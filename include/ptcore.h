@@ -214,11 +214,15 @@ int32_t pt_shard_tiles(int32_t width, int32_t height, const pt_shard *shard, int
 int32_t pt_render_tiles_device(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, const pt_shard *shard,
                                void *d_tiles_rgba, void *d_tiles_accum, void *stream, pt_stats *stats);
 
-/* Scatters gathered tile buffers ([count shards][ntiles_local(s)] concatenated in
- * shard order) into a row-major frame on the device: d_rgba = height rows of
- * `stride` bytes; d_accum optional width*height*3 doubles. */
-int32_t pt_untile_device(pt_ctx *ctx, int32_t width, int32_t height, int32_t shard_count, const void *d_tiles_rgba,
-                         const void *d_tiles_accum, void *d_rgba, int32_t stride, void *d_accum, void *stream);
+/* Scatters gathered tile buffers into a row-major frame on the device: d_rgba =
+ * height rows of `stride` bytes (stride % 4 == 0); d_accum optional width*height*3
+ * doubles.  The gathered buffer holds shard 0's tiles, then shard 1's, ...; shard k
+ * starts at tile k*shard_stride_tiles, or right after shard k-1 when
+ * shard_stride_tiles == 0 (compact).  A fixed stride is what an equal-sized
+ * collective gather (ncclGather / torch.distributed.gather) produces. */
+int32_t pt_untile_device(pt_ctx *ctx, int32_t width, int32_t height, int32_t shard_count, int32_t shard_stride_tiles,
+                         const void *d_tiles_rgba, const void *d_tiles_accum, void *d_rgba, int32_t stride,
+                         void *d_accum, void *stream);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,8 @@ SYMBOLS = [
                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("pt_render_tiles_device", C.c_int32, [_vp, C.POINTER(PtScene), C.POINTER(PtConfig), C.POINTER(PtShard), _vp, _vp,
                                             _vp, C.POINTER(PtStats)]),
-    ("pt_untile_device", C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
+    ("pt_untile_device", C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp,
+                                      _vp]),
 ]
 
 

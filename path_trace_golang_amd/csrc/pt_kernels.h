@@ -625,6 +625,7 @@ struct UntileArgs {
     double *accum;               // width*height*3 (or null)
     uint32_t *u32a, *u32b;       // width*height (or null)
     int32_t width, height, ntx, nty, stride, shard_count;
+    int32_t shard_stride_tiles;  // 0: shards are packed back to back
 };
 
 __global__ __launch_bounds__(PT_BLOCK) void untile_kernel(const UntileArgs U) {
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(PT_BLOCK) void untile_kernel(const UntileArgs U) {
     const uint32_t k = t % (uint32_t)U.shard_count, lt = t / (uint32_t)U.shard_count;
     // tiles owned by shards 0..k-1
     const uint32_t q = ntiles / (uint32_t)U.shard_count, r = ntiles % (uint32_t)U.shard_count;
-    const uint32_t before = k * q + (k < r ? k : r);
+    const uint32_t before = U.shard_stride_tiles ? k * (uint32_t)U.shard_stride_tiles : k * q + (k < r ? k : r);
     const size_t pix = ((size_t)before + lt) * 1024u + (y & 31u) * 32u + (x & 31u);
     if (U.rgba)
         *reinterpret_cast<uint32_t *>(U.rgba + (size_t)y * (size_t)U.stride + (size_t)x * 4u) =

@@ -845,10 +845,16 @@ int32_t pt_render_tiles_device(pt_ctx *ctx, const pt_scene *scene, const pt_conf
     return rc;
 }
 
-int32_t pt_untile_device(pt_ctx *ctx, int32_t width, int32_t height, int32_t shard_count, const void *d_tiles_rgba,
-                         const void *d_tiles_accum, void *d_rgba, int32_t stride, void *d_accum, void *stream) {
+int32_t pt_untile_device(pt_ctx *ctx, int32_t width, int32_t height, int32_t shard_count, int32_t shard_stride_tiles,
+                         const void *d_tiles_rgba, const void *d_tiles_accum, void *d_rgba, int32_t stride, void *d_accum,
+                         void *stream) {
     if (!ctx) return fail(PT_ERR_INVALID, "ctx is null");
     if (width <= 0 || height <= 0 || shard_count <= 0) return fail(PT_ERR_INVALID, "bad frame or shard count");
+    {
+        const int32_t nt = ((width + 31) / 32) * ((height + 31) / 32);
+        if (shard_stride_tiles != 0 && shard_stride_tiles < tiles_of_shard(nt, pt_shard{0, shard_count}))
+            return fail(PT_ERR_INVALID, "shard_stride_tiles smaller than the largest shard");
+    }
     if (d_rgba && (stride < width * 4 || stride % 4 != 0)) return fail(PT_ERR_INVALID, "stride must be a multiple of 4 and >= 4*width");
     if (d_rgba && !d_tiles_rgba) return fail(PT_ERR_INVALID, "d_tiles_rgba is null");
     if (d_accum && !d_tiles_accum) return fail(PT_ERR_INVALID, "d_tiles_accum is null");
@@ -862,7 +868,7 @@ int32_t pt_untile_device(pt_ctx *ctx, int32_t width, int32_t height, int32_t sha
     U.accum = static_cast<double *>(d_accum);
     U.width = width; U.height = height;
     U.ntx = (width + 31) / 32; U.nty = (height + 31) / 32;
-    U.stride = stride; U.shard_count = shard_count;
+    U.stride = stride; U.shard_count = shard_count; U.shard_stride_tiles = shard_stride_tiles;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : d.own_stream;
     hipLaunchKernelGGL(ptk::untile_kernel, dim3((unsigned)U.ntx, (unsigned)U.nty, 4), dim3(PT_BLOCK), 0, s, U);
     HIP_TRY(hipGetLastError());
