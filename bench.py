@@ -63,7 +63,7 @@ def main() -> int:
     import torch  # first: libptcore must resolve libamdhip64.so.7 to the copy torch already loaded
     import torch.distributed as dist
 
-    from path_trace_golang_amd import capi, hip, scene
+    from path_trace_golang_amd import capi, distributed, hip, scene
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,24 +98,30 @@ def main() -> int:
     stride_tiles = ntl_max.value
 
     tiles = torch.zeros(stride_tiles * 4096, dtype=torch.uint8, device=dev)
-    gathered = None
+    scratch = None
     frame = None
+    packed = None
     if rank == 0:
-        gathered = [torch.empty_like(tiles) for _ in range(world)] if world > 1 else None
+        scratch = [torch.empty_like(tiles) for _ in range(world)] if world > 1 else None
+        packed = torch.empty(world * stride_tiles * 4096, dtype=torch.uint8, device=dev) if world > 1 else None
         frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
+
+    def untile(bufs, stride):
+        src = bufs[0]
+        if len(bufs) > 1:
+            torch.cat(bufs, out=packed)
+            src = packed
+        capi.check(L.pt_untile_device(ctx.handle, W, H, world, stride, C.c_void_p(src.data_ptr()), None,
+                                      C.c_void_p(frame.data_ptr()), W * 4, None, C.c_void_p(stream.cuda_stream)))
+        return frame
 
     def step():
         st = capi.PtStats()
         capi.check(L.pt_render_tiles_device(ctx.handle, C.byref(flat.c), C.byref(cfg), C.byref(shard),
                                             C.c_void_p(tiles.data_ptr()), None, C.c_void_p(stream.cuda_stream),
                                             C.byref(st)))
-        if world > 1:
-            dist.gather(tiles, gathered, dst=0)
-        if rank == 0:
-            src = torch.cat(gathered) if world > 1 else tiles
-            capi.check(L.pt_untile_device(ctx.handle, W, H, world, stride_tiles, C.c_void_p(src.data_ptr()), None,
-                                          C.c_void_p(frame.data_ptr()), W * 4, None, C.c_void_p(stream.cuda_stream)))
+        distributed.assemble_frame(tiles, W, H, rank, world, untile, scratch)
         return st
 
     def fence():

@@ -224,6 +224,16 @@ int32_t pt_untile_device(pt_ctx *ctx, int32_t width, int32_t height, int32_t sha
                          const void *d_tiles_rgba, const void *d_tiles_accum, void *d_rgba, int32_t stride,
                          void *d_accum, void *stream);
 
+/*
+ * Diagnostics only (not part of the rendering boundary): with PTCORE_PROFILE=1 in the
+ * environment at pt_create, the trace kernel runs a build that counts, per code
+ * section, wave executions, active lanes and shader-clock cycles.  Copies up to n
+ * values of the last collected frame ([section][executions, lanes, cycles]) and
+ * returns the number available (negative status is impossible: errors return PT_ERR_*
+ * as positive codes <= 5, counts are >= 6).
+ */
+int32_t pt_debug_profile(pt_ctx *ctx, uint64_t *out, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,11 @@
 This is the only way Python reaches the renderer: there is no Python or CPU
 rendering path in this package.  If the library has not been built, or no HIP
 device is present, the calls raise -- they never fall back.
+
+A process that also uses torch must `import torch` BEFORE the first capi.load(): torch bundles
+its own libamdhip64.so.7, and loading it first lets libptcore.so bind to that same copy (one HIP
+runtime, so torch streams and device pointers are valid inside libptcore).  The other order
+loads two HIP runtimes and torch then reports no GPUs.
 """
 from __future__ import annotations
 
@@ -89,6 +94,7 @@ SYMBOLS = [
                                             _vp, C.POINTER(PtStats)]),
     ("pt_untile_device", C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp,
                                       _vp]),
+    ("pt_debug_profile", C.c_int32, [_vp, C.POINTER(C.c_uint64), C.c_int32]),
 ]
 
 

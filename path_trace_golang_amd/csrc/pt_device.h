@@ -90,6 +90,7 @@ struct TraceBuffers {
     uint32_t *job_draw;   // [njobs] or null
     unsigned int *queue;  // job queue head
     unsigned long long *counters;  // [4]: segments, exit_scans, draws, samples
+    unsigned long long *prof;      // diagnostic build only: [SEC_COUNT][3] executions, lanes, cycles
 };
 
 }  // namespace ptd

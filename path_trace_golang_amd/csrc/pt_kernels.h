@@ -78,7 +78,13 @@ __device__ __forceinline__ void reflect_vec(double vx, double vy, double vz, dou
     rz = vz - nz * 2 * dot;
 }
 
-template <bool STATS>
+// Section ids of the diagnostic build (PROF = true): per section the kernel counts wave
+// executions, active lanes and shader-clock cycles (leader lane only).  The shipping
+// instantiations have PROF = false and contain none of this.
+enum { SEC_ITER = 0, SEC_RAYGEN, SEC_LENS, SEC_SCAN, SEC_SPH_ROOT, SEC_SPH_ROOT2, SEC_HITREC, SEC_COSINE,
+       SEC_DIEL, SEC_EXITPOST, SEC_RR, SEC_FINISH, SEC_SKY, SEC_UNITDIR, SEC_COUNT };
+
+template <bool STATS, bool PROF>
 __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const DevCamera cam, const DevSky sky,
                                                            const TraceBuffers B) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -119,12 +125,32 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
     uint32_t cur = 0, end = 0;
     bool exhausted = false;
 
+    // diagnostic counters (registers; only materialised when PROF)
+    uint32_t p_exec[SEC_COUNT], p_lanes[SEC_COUNT];
+    unsigned long long p_cyc[SEC_COUNT];
+    if (PROF) {
+#pragma unroll
+        for (int i = 0; i < SEC_COUNT; i++) { p_exec[i] = 0; p_lanes[i] = 0; p_cyc[i] = 0; }
+    }
+#define SEC_BEGIN(id)                                                                 \
+    unsigned long long t_##id = 0;                                                    \
+    bool lead_##id = false;                                                           \
+    if (PROF) {                                                                       \
+        const uint64_t m_ = __ballot(1);                                              \
+        lead_##id = lane == (uint32_t)(__ffsll((long long)m_) - 1);                   \
+        p_lanes[id]++;                                                                \
+        if (lead_##id) { p_exec[id]++; t_##id = __builtin_amdgcn_s_memtime(); }       \
+    }
+#define SEC_END(id) \
+    if (PROF && lead_##id) p_cyc[id] += __builtin_amdgcn_s_memtime() - t_##id;
+
 #define PT_DRAW(var)                 \
     double var = ptm::stream_next(rs); \
     c_draw++;                        \
     if (STATS) j_draw++;
 
     for (;;) {
+        SEC_BEGIN(SEC_ITER)
         // ------------------------------------------------------------ regeneration
         const uint64_t need = __ballot(!active);
         if (need != 0) {
@@ -158,6 +184,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 const uint32_t x = tx * 32u + (sb & 3u) * 8u + (p & 7u);
                 const uint32_t y = ty * 32u + (sb >> 2) * 8u + (p >> 3);
                 if (x < (uint32_t)F.width && y < (uint32_t)F.height) {
+                    SEC_BEGIN(SEC_RAYGEN)
                     job = myjob;
                     active = true;
                     mode = 0;
@@ -182,6 +209,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     if (cam.lens_radius > 0) {
                         double rx, ry, rz;
                         for (;;) {  // randomInUnitSphere, math.go:74-84
+                            SEC_BEGIN(SEC_LENS)
                             PT_DRAW(d0)
                             PT_DRAW(d1)
                             PT_DRAW(d2)
@@ -189,6 +217,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                             ry = d1 * 2 - 1;
                             rz = d2 * 2 - 1;
                             const double lenSq = rx * rx + ry * ry + rz * rz;
+                            SEC_END(SEC_LENS)
                             if (lenSq >= 1.0) continue;
                             break;
                         }
@@ -211,6 +240,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                         dy = ay - cam.origin[1];
                         dz = az - cam.origin[2];
                     }
+                    SEC_END(SEC_RAYGEN)
                 }
             }
             if (__ballot(active) == 0) break;  // queue drained and every lane idle
@@ -221,6 +251,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
 
         if (active) {
             // -------------------------------------------------------- scan
+            SEC_BEGIN(SEC_SCAN)
             const double tmin = mode ? 0.0001 : 0.001;  // renderer.go:322 / :292
             double tmax = ptm::max_float64();
             int best = -1;
@@ -241,14 +272,18 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     const double c = ocLenSq - o.radius_sq;
                     const double disc = halfB * halfB - a * c;
                     if (!(disc < 0)) {
+                        SEC_BEGIN(SEC_SPH_ROOT)
                         const double sq = ptm::f_sqrt(disc);
                         double root = (-halfB - sq) / a;
                         valid = true;
                         if (root < tmin || root > tmax) {
+                            SEC_BEGIN(SEC_SPH_ROOT2)
                             root = (-halfB + sq) / a;
                             if (root < tmin || root > tmax) valid = false;
+                            SEC_END(SEC_SPH_ROOT2)
                         }
                         t = root;
+                        SEC_END(SEC_SPH_ROOT)
                     }
                 } else if (kind == KIND_BOX) {  // objects.go:141-179
                     double t0 = tmin, t1 = tmax;
@@ -297,6 +332,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 }
             }
 
+            SEC_END(SEC_SCAN)
             // -------------------------------------------------------- shade
             bool do_rr = false;
             double attx = 1, atty = 1, attz = 1;
@@ -305,6 +341,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 if (STATS) j_seg++;
                 if (best < 0) {
                     // sky closure, renderer.go:56-92
+                    SEC_BEGIN(SEC_SKY)
                     finished = true;
                     if (sky.kind == 1) {
                         const double dirLen = ptm::f_sqrt(dx * dx + dy * dy + dz * dz);
@@ -321,7 +358,9 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     } else {
                         termx = sky.c0[0]; termy = sky.c0[1]; termz = sky.c0[2];
                     }
+                    SEC_END(SEC_SKY)
                 } else {
+                    SEC_BEGIN(SEC_HITREC)
                     const DevObj &o = s_obj[best];
                     const int kind = o.kind & 0xff;
                     const double px = ox + dx * tmax, py = oy + dy * tmax, pz = oz + dz * tmax;
@@ -332,6 +371,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     const int mi = o.mat;
                     const DevMat &m = s_mat[mi];
                     const int typ = m.typ;
+                    SEC_END(SEC_HITREC)
                     if (typ == MAT_EMISSIVE) {  // materials.go:67-72, :202-203
                         finished = true;
                         termx = m.emit[0]; termy = m.emit[1]; termz = m.emit[2];
@@ -340,6 +380,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                         double ux = 0, uy = 0, uz = 0, rfx = 0, rfy = 0, rfz = 0;
                         bool zero_dir = false;
                         if (typ != MAT_LAMBERT) {
+                            SEC_BEGIN(SEC_UNITDIR)
                             const double dirLen = ptm::f_sqrt(dx * dx + dy * dy + dz * dz);
                             if (dirLen == 0) {
                                 zero_dir = true;
@@ -348,6 +389,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                                 ux = dx * invLen; uy = dy * invLen; uz = dz * invLen;
                                 reflect_vec(ux, uy, uz, nx, ny, nz, rfx, rfy, rfz);
                             }
+                            SEC_END(SEC_UNITDIR)
                         }
                         if (zero_dir) {
                             finished = true;  // scatter fails -> emitted (0)
@@ -355,6 +397,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                             double ndx = rfx, ndy = rfy, ndz = rfz;  // mirror / smooth metal / reflecting glass
                             const bool cosine = (typ == MAT_LAMBERT) || (typ == MAT_METAL && m.rough > 1e-6);
                             if (cosine) {
+                                SEC_BEGIN(SEC_COSINE)
                                 // randomCosineDirection, math.go:94-131, about the normal (lambert)
                                 // or about the mirror direction (rough metal, materials.go:119)
                                 const double wx = (typ == MAT_LAMBERT) ? nx : rfx;
@@ -423,8 +466,10 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                                     if (dot <= 0) { mx = rfx; my = rfy; mz = rfz; }
                                     ndx = mx; ndy = my; ndz = mz;
                                 }
+                                SEC_END(SEC_COSINE)
                             }
                             if (typ == MAT_DIELECTRIC) {  // materials.go:162-200
+                                SEC_BEGIN(SEC_DIEL)
                                 const double ratio = ff ? 1.0 / m.ior : m.ior;
                                 const double cosTheta = ptm::go_min(-(ux * nx + uy * ny + uz * nz), 1.0);
                                 const double sinTheta = ptm::f_sqrt(1.0 - cosTheta * cosTheta);
@@ -445,6 +490,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                                     const double par = -ptm::f_sqrt(ptm::f_abs(1.0 - perpLenSq));
                                     ndx = qx + nx * par; ndy = qy + ny * par; ndz = qz + nz * par;
                                 }
+                                SEC_END(SEC_DIEL)
                             } else {
                                 attx = m.albedo[0]; atty = m.albedo[1]; attz = m.albedo[2];
                             }
@@ -463,6 +509,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 }
             } else {
                 // exit search done (renderer.go:352-370); the hit point of the entry is the ray origin
+                SEC_BEGIN(SEC_EXITPOST)
                 if (best >= 0) {
                     const double px = ox + dx * tmax, py = oy + dy * tmax, pz = oz + dz * tmax;
                     const double ex = px - ox, ey = py - oy, ez = pz - oz;
@@ -477,10 +524,12 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 }
                 mode = 0;
                 do_rr = true;
+                SEC_END(SEC_EXITPOST)
             }
 
             // ------------------------------------------------------------ roulette + advance
             if (do_rr) {
+                SEC_BEGIN(SEC_RR)
                 if (depth <= 3) {  // renderer.go:375-393
                     const double maxAtt = ptm::go_max(attx, ptm::go_max(atty, attz));
                     if (maxAtt < 1e-6) {
@@ -500,9 +549,11 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     depth--;
                     if (depth <= 0) finished = true;  // renderer.go:287-289 contributes zero
                 }
+                SEC_END(SEC_RR)
             }
 
             if (finished) {
+                SEC_BEGIN(SEC_FINISH)
                 B.L[job] = Tx * termx;
                 B.L[(size_t)F.njobs + job] = Ty * termy;
                 B.L[2 * (size_t)F.njobs + job] = Tz * termz;
@@ -511,10 +562,22 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     B.job_draw[job] = j_draw;
                 }
                 active = false;
+                SEC_END(SEC_FINISH)
             }
         }
+        SEC_END(SEC_ITER)
     }
 #undef PT_DRAW
+#undef SEC_BEGIN
+#undef SEC_END
+    if (PROF) {
+#pragma unroll
+        for (int i = 0; i < SEC_COUNT; i++) {
+            atomicAdd(&B.prof[3 * i], (unsigned long long)p_exec[i]);
+            atomicAdd(&B.prof[3 * i + 1], (unsigned long long)p_lanes[i]);
+            atomicAdd(&B.prof[3 * i + 2], p_cyc[i]);
+        }
+    }
 
     // counters: one atomic per wave
     const uint32_t w_seg = wave_sum(c_seg), w_exit = wave_sum(c_exit), w_draw = wave_sum(c_draw),

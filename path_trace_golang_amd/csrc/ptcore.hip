@@ -30,6 +30,7 @@ using namespace ptd;
 namespace {
 
 thread_local std::string g_last_error;
+unsigned long long g_profile_scratch[3 * ptk::SEC_COUNT] = {};
 
 int32_t fail(int32_t code, const std::string &msg) {
     g_last_error = msg;
@@ -84,6 +85,7 @@ struct Device {
     DevBuf<uint32_t> tiles_seg, tiles_draw;
     DevBuf<unsigned int> queue;
     DevBuf<unsigned long long> counters;
+    DevBuf<unsigned long long> prof;
     std::vector<EventPair> ev_trace, ev_resolve;
     size_t n_trace = 0, n_resolve = 0;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
@@ -125,6 +127,8 @@ struct pt_ctx {
     size_t l_budget_bytes = (size_t)2 << 30;
     uint32_t claim = 256;
     int max_blocks_per_cu = 8;
+    bool profile_sections = false;  // PTCORE_PROFILE=1: diagnostic kernel build with per-section counters
+    unsigned long long last_profile[3 * ptk::SEC_COUNT] = {};
 };
 
 namespace {
@@ -323,6 +327,10 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, cons
     HIP_TRY(d.queue.reserve(1));
     HIP_TRY(d.counters.reserve(4));
     HIP_TRY(hipMemsetAsync(d.counters.p, 0, 4 * sizeof(unsigned long long), d.stream));
+    if (ctx->profile_sections) {
+        HIP_TRY(d.prof.reserve(3 * ptk::SEC_COUNT));
+        HIP_TRY(hipMemsetAsync(d.prof.p, 0, 3 * ptk::SEC_COUNT * sizeof(unsigned long long), d.stream));
+    }
     const size_t ns = std::max<uint32_t>(1, d.nslots);
     HIP_TRY(d.acc.reserve(3 * ns));
     if (fr.stats_on) {
@@ -343,10 +351,12 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, cons
     const size_t lds = (size_t)fr.nobj * sizeof(DevObj) + (size_t)fr.nmat * sizeof(DevMat);
     if (lds > 160 * 1024) return fail(PT_ERR_INVALID, "scene does not fit the 160 KiB LDS of a CU");
     int nb = 0;
-    if (fr.stats_on)
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<true>, PT_BLOCK, lds));
+    if (ctx->profile_sections)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<false, true>, PT_BLOCK, lds));
+    else if (fr.stats_on)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<true, false>, PT_BLOCK, lds));
     else
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<false>, PT_BLOCK, lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<false, false>, PT_BLOCK, lds));
     d.blocks_per_cu = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
     return PT_OK;
 }
@@ -372,6 +382,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     B.job_draw = fr.stats_on ? d.job_draw.p : nullptr;
     B.queue = d.queue.p;
     B.counters = d.counters.p;
+    B.prof = ctx->profile_sections ? d.prof.p : nullptr;
 
     if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + 1)) return rc;
     if (int32_t rc = dev_events(d, d.ev_resolve, d.n_resolve + 1)) return rc;
@@ -394,10 +405,12 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
         grid = std::max(1u, std::min(grid, (waves_needed + 3u) / 4u));
         EventPair &e = d.ev_trace[d.n_trace++];
         HIP_TRY(hipEventRecord(e.a, d.stream));
-        if (fr.stats_on)
-            hipLaunchKernelGGL(ptk::trace_kernel<true>, dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
+        if (ctx->profile_sections)
+            hipLaunchKernelGGL((ptk::trace_kernel<false, true>), dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
+        else if (fr.stats_on)
+            hipLaunchKernelGGL((ptk::trace_kernel<true, false>), dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
         else
-            hipLaunchKernelGGL(ptk::trace_kernel<false>, dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
+            hipLaunchKernelGGL((ptk::trace_kernel<false, false>), dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e.b, d.stream));
     }
@@ -475,6 +488,8 @@ int32_t dev_collect(Device &d, pt_stats *st, int slot) {
     st->exit_scans += c[1];
     st->draws += c[2];
     st->samples += c[3];
+    if (d.prof.p && slot == 0)
+        HIP_TRY(hipMemcpy(g_profile_scratch, d.prof.p, sizeof g_profile_scratch, hipMemcpyDeviceToHost));
     double tr = 0, rs = 0;
     for (size_t i = 0; i < d.n_trace; i++) {
         float ms = 0;
@@ -576,6 +591,7 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
         long c = std::atol(e);
         if (c >= 64 && c % 64 == 0) ctx->claim = (uint32_t)c;
     }
+    if (const char *e = std::getenv("PTCORE_PROFILE")) ctx->profile_sections = std::atoi(e) != 0;
     if (const char *e = std::getenv("PTCORE_BLOCKS_PER_CU")) {
         long c = std::atol(e);
         if (c >= 1 && c <= 8) ctx->max_blocks_per_cu = (int)c;
@@ -609,6 +625,7 @@ void pt_destroy(pt_ctx *ctx) {
         if (hipSetDevice(d.ordinal) != hipSuccess) continue;
         if (d.own_stream) (void)hipStreamSynchronize(d.own_stream);
         d.objs.release(); d.mats.release(); d.L.release(); d.job_seg.release(); d.job_draw.release();
+        d.prof.release();
         d.acc.release(); d.acc_seg.release(); d.acc_draw.release(); d.tiles_rgba.release();
         d.tiles_accum.release(); d.tiles_seg.release(); d.tiles_draw.release(); d.queue.release();
         d.counters.release();
@@ -624,6 +641,13 @@ void pt_destroy(pt_ctx *ctx) {
         ctx->f_draw.release();
     }
     delete ctx;
+}
+
+int32_t pt_debug_profile(pt_ctx *ctx, uint64_t *out, int32_t n) {
+    if (!ctx || !out) return fail(PT_ERR_INVALID, "null argument");
+    if (!ctx->profile_sections) return fail(PT_ERR_STATE, "set PTCORE_PROFILE=1 before pt_create");
+    for (int32_t i = 0; i < n && i < 3 * ptk::SEC_COUNT; i++) out[i] = g_profile_scratch[i];
+    return 3 * ptk::SEC_COUNT;
 }
 
 int32_t pt_shard_tiles(int32_t width, int32_t height, const pt_shard *shard, int32_t *ntiles_local, int32_t *ntiles_x,

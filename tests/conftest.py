@@ -31,6 +31,10 @@ def oracle():
 @pytest.fixture(scope="session")
 def gpu_ctx():
     """One pt_ctx for the whole GPU session; fails loudly if the HIP library is missing."""
+    # some gpu tests hand torch device memory to the C ABI: torch must load ITS libamdhip64.so.7 before
+    # libptcore.so is loaded, so both share one HIP runtime (the loader matches the SONAME)
+    import torch  # noqa: F401
+
     from path_trace_golang_amd import capi
 
     capi.load()

@@ -1,0 +1,84 @@
+"""C-ABI surface on CPU: libptcore.so loads, exports every symbol include/ptcore.h declares, and
+fails loudly (no fallback) when there is no HIP device.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ptcore.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from path_trace_golang_amd import build, capi
+
+    build.build_core()
+    lib = capi.load()
+    declared = _declared_symbols()
+    assert "pt_render" in declared and "pt_render_tiles_device" in declared and len(declared) >= 12
+    bound = {name for name, _, _ in capi.SYMBOLS}
+    for sym in declared:
+        assert hasattr(lib, sym), sym + " is declared in ptcore.h but not exported by libptcore.so"
+        assert sym in bound, sym + " has no ctypes prototype in capi.SYMBOLS"
+    assert lib.pt_abi_version() == capi.PT_ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    from path_trace_golang_amd import capi
+
+    # sizes implied by the C declarations (LP64, natural alignment)
+    assert C.sizeof(capi.PtMaterial) == 8 + 8 * (3 + 1 + 1 + 3 + 1 + 3 + 1)
+    assert C.sizeof(capi.PtObject) == 8 + 48
+    assert C.sizeof(capi.PtCamera) == 13 * 8
+    assert C.sizeof(capi.PtSky) == 8 + 12 * 8
+    assert C.sizeof(capi.PtScene) == 13 * 8 + 104 + 8 + 16
+    assert C.sizeof(capi.PtConfig) == 32
+    assert C.sizeof(capi.PtStats) == 4 * 8 + 4 * 8 + 4 * 4 + 8 * 8
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    from path_trace_golang_amd import capi
+
+    if capi.device_count() > 0:
+        pytest.skip("a HIP device is present; the no-device contract is checked in the build container")
+    lib = capi.load()
+    n = C.c_int32(-1)
+    assert lib.pt_device_count(C.byref(n)) == capi.PT_ERR_NO_DEVICE and n.value == 0
+    h = C.c_void_p()
+    assert lib.pt_create(None, 1, C.byref(h)) == capi.PT_ERR_NO_DEVICE and not h.value
+    assert b"no HIP device" in lib.pt_last_error()
+    with pytest.raises(capi.PtError):
+        capi.Context(ndev=1)
+
+
+def test_product_never_imports_the_oracle():
+    # the oracle is test infrastructure: nothing under path_trace_golang_amd/ or include/ may reference it
+    bad = []
+    for base in ("path_trace_golang_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c")):
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    if re.search(r"\boracle\b|libptoracle|pt_oracle|\bora_", text):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_shard_tile_counts_agree_with_python_tiling():
+    from path_trace_golang_amd import capi, tiling
+
+    lib = capi.load()
+    for (w, h, n) in [(1920, 1080, 8), (80, 70, 2), (33, 31, 3), (3840, 2160, 8), (400, 225, 1)]:
+        for k in range(n):
+            sh = capi.PtShard(k, n)
+            a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+            assert lib.pt_shard_tiles(w, h, C.byref(sh), C.byref(a), C.byref(b), C.byref(c)) == 0
+            assert a.value == len(tiling.shard_tiles(w, h, k, n)) and (b.value, c.value) == tiling.tile_grid(w, h)
+    bad = capi.PtShard(3, 2)
+    assert lib.pt_shard_tiles(64, 64, C.byref(bad), None, None, None) == capi.PT_ERR_INVALID

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Runs the diagnostic (PTCORE_PROFILE=1) build on a workload and prints per-section shares.
+   python tools/section_profile.py [scene] [w] [h] [spp] [depth]"""
+import ctypes as C, os, sys
+os.environ["PTCORE_PROFILE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from path_trace_golang_amd import capi, hip, scene
+name = sys.argv[1] if len(sys.argv) > 1 else "gpu_showcase"
+w, h, spp, d = (int(x) for x in (sys.argv[2:6] if len(sys.argv) >= 6 else (1920, 1080, 42, 8)))
+SEC = ["iter", "raygen", "lens", "scan", "sph_root", "sph_root2", "hitrec", "cosine", "diel", "exitpost", "rr",
+       "finish", "sky", "unitdir"]
+ctx = capi.Context(ndev=1)
+sc = scene.load("scenes/%s.json" % name)
+img = np.zeros((h, w, 4), np.uint8)
+st = hip.render(sc, hip.RenderConfig(w, h, spp, d, 1), img, ctx=ctx)
+buf = (C.c_uint64 * (3 * len(SEC)))()
+n = capi.load().pt_debug_profile(ctx.handle, buf, len(buf))
+it_exec, it_lanes, it_cyc = buf[0], buf[1], buf[2]
+print("%s %dx%d spp %d depth %d: trace %.1f ms, %d segs, %d exits" % (name, w, h, spp, d, st["trace_ms"], st["segments"], st["exit_scans"]))
+print("%-10s %14s %10s %8s %12s %10s" % ("section", "wave-execs", "exec/iter", "lanes%", "cycles-share", "cyc/exec"))
+for i, s in enumerate(SEC):
+    e, l, c = buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]
+    print("%-10s %14d %10.3f %8.1f %12.3f %10.0f" % (s, e, e / max(it_exec, 1), 100.0 * l / max(64 * e, 1), c / max(it_cyc, 1), c / max(e, 1)))
