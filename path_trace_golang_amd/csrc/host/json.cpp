@@ -1,0 +1,274 @@
+#include "json.hpp"
+
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+
+namespace pthost {
+namespace json {
+
+namespace {
+
+bool iequals(const std::string &a, const std::string &b) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); i++)
+        if (std::tolower((unsigned char)a[i]) != std::tolower((unsigned char)b[i])) return false;
+    return true;
+}
+
+struct Parser {
+    const std::string &s;
+    size_t i = 0;
+    explicit Parser(const std::string &t) : s(t) {}
+
+    [[noreturn]] void fail(const char *what) const {
+        throw std::runtime_error(std::string("invalid JSON at offset ") + std::to_string(i) + ": " + what);
+    }
+    void ws() {
+        while (i < s.size() && (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r')) i++;
+    }
+    void append_utf8(std::string &o, unsigned cp) {
+        if (cp < 0x80) o += (char)cp;
+        else if (cp < 0x800) { o += (char)(0xC0 | (cp >> 6)); o += (char)(0x80 | (cp & 0x3F)); }
+        else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+        else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+    }
+    unsigned hex4() {
+        if (i + 4 > s.size()) fail("short \\u escape");
+        unsigned v = 0;
+        for (int k = 0; k < 4; k++) {
+            char c = s[i++];
+            v <<= 4;
+            if (c >= '0' && c <= '9') v |= (unsigned)(c - '0');
+            else if (c >= 'a' && c <= 'f') v |= (unsigned)(c - 'a' + 10);
+            else if (c >= 'A' && c <= 'F') v |= (unsigned)(c - 'A' + 10);
+            else fail("bad \\u escape");
+        }
+        return v;
+    }
+    std::string string_lit() {
+        if (s[i] != '"') fail("expected string");
+        i++;
+        std::string o;
+        while (true) {
+            if (i >= s.size()) fail("unterminated string");
+            char c = s[i++];
+            if (c == '"') break;
+            if ((unsigned char)c < 0x20) fail("control character in string");
+            if (c != '\\') { o += c; continue; }
+            if (i >= s.size()) fail("unterminated escape");
+            char e = s[i++];
+            switch (e) {
+                case '"': o += '"'; break;
+                case '\\': o += '\\'; break;
+                case '/': o += '/'; break;
+                case 'b': o += '\b'; break;
+                case 'f': o += '\f'; break;
+                case 'n': o += '\n'; break;
+                case 'r': o += '\r'; break;
+                case 't': o += '\t'; break;
+                case 'u': {
+                    unsigned cp = hex4();
+                    if (cp >= 0xD800 && cp < 0xDC00 && i + 1 < s.size() && s[i] == '\\' && s[i + 1] == 'u') {
+                        i += 2;
+                        unsigned lo = hex4();
+                        if (lo >= 0xDC00 && lo < 0xE000) cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                        else cp = 0xFFFD;
+                    }
+                    append_utf8(o, cp);
+                    break;
+                }
+                default: fail("bad escape");
+            }
+        }
+        return o;
+    }
+    ValuePtr value() {
+        ws();
+        if (i >= s.size()) fail("unexpected end of input");
+        auto v = std::make_shared<Value>();
+        char c = s[i];
+        if (c == '{') {
+            v->kind = Value::Object;
+            i++;
+            ws();
+            if (i < s.size() && s[i] == '}') { i++; return v; }
+            while (true) {
+                ws();
+                if (i >= s.size() || s[i] != '"') fail("expected object key");
+                std::string k = string_lit();
+                ws();
+                if (i >= s.size() || s[i] != ':') fail("expected ':'");
+                i++;
+                v->obj.emplace_back(k, value());
+                ws();
+                if (i < s.size() && s[i] == ',') { i++; continue; }
+                if (i < s.size() && s[i] == '}') { i++; break; }
+                fail("expected ',' or '}'");
+            }
+        } else if (c == '[') {
+            v->kind = Value::Array;
+            i++;
+            ws();
+            if (i < s.size() && s[i] == ']') { i++; return v; }
+            while (true) {
+                v->arr.push_back(value());
+                ws();
+                if (i < s.size() && s[i] == ',') { i++; continue; }
+                if (i < s.size() && s[i] == ']') { i++; break; }
+                fail("expected ',' or ']'");
+            }
+        } else if (c == '"') {
+            v->kind = Value::String;
+            v->str = string_lit();
+        } else if (s.compare(i, 4, "true") == 0) {
+            v->kind = Value::Bool; v->b = true; i += 4;
+        } else if (s.compare(i, 5, "false") == 0) {
+            v->kind = Value::Bool; v->b = false; i += 5;
+        } else if (s.compare(i, 4, "null") == 0) {
+            v->kind = Value::Null; i += 4;
+        } else if (c == '-' || (c >= '0' && c <= '9')) {
+            size_t j = i;
+            if (s[j] == '-') j++;
+            if (j >= s.size() || !(s[j] >= '0' && s[j] <= '9')) fail("bad number");
+            if (s[j] == '0') j++;
+            else while (j < s.size() && std::isdigit((unsigned char)s[j])) j++;
+            if (j < s.size() && s[j] == '.') {
+                j++;
+                if (j >= s.size() || !std::isdigit((unsigned char)s[j])) fail("bad fraction");
+                while (j < s.size() && std::isdigit((unsigned char)s[j])) j++;
+            }
+            if (j < s.size() && (s[j] == 'e' || s[j] == 'E')) {
+                j++;
+                if (j < s.size() && (s[j] == '+' || s[j] == '-')) j++;
+                if (j >= s.size() || !std::isdigit((unsigned char)s[j])) fail("bad exponent");
+                while (j < s.size() && std::isdigit((unsigned char)s[j])) j++;
+            }
+            v->kind = Value::Number;
+            // strtod is correctly rounded in glibc, like Go's strconv.ParseFloat
+            v->num = std::strtod(s.substr(i, j - i).c_str(), nullptr);
+            i = j;
+        } else {
+            fail("unexpected character");
+        }
+        return v;
+    }
+};
+
+}  // namespace
+
+const Value *Value::get(const std::string &key) const {
+    if (kind != Object) return nullptr;
+    const Value *found = nullptr;
+    for (const auto &kv : obj)
+        if (kv.first == key) found = kv.second.get();
+    if (!found)
+        for (const auto &kv : obj)
+            if (iequals(kv.first, key)) found = kv.second.get();
+    if (found && found->kind == Null) return nullptr;
+    return found;
+}
+double Value::number(const std::string &key) const {
+    const Value *v = get(key);
+    return (v && v->kind == Number) ? v->num : 0.0;
+}
+long long Value::integer(const std::string &key) const {
+    const Value *v = get(key);
+    return (v && v->kind == Number) ? (long long)v->num : 0;
+}
+std::string Value::string(const std::string &key) const {
+    const Value *v = get(key);
+    return (v && v->kind == String) ? v->str : std::string();
+}
+bool Value::boolean(const std::string &key) const {
+    const Value *v = get(key);
+    return v && v->kind == Bool && v->b;
+}
+
+ValuePtr parse(const std::string &text) {
+    Parser p(text);
+    return p.value();
+}
+
+std::string format_number(double v) {
+    if (std::isnan(v) || std::isinf(v)) throw std::runtime_error("json: unsupported value (NaN/Inf)");
+    if (v == 0) return std::signbit(v) ? "-0" : "0";
+    // shortest decimal that round-trips
+    char buf[40];
+    for (int prec = 1; prec <= 17; prec++) {
+        std::snprintf(buf, sizeof buf, "%.*g", prec, v);
+        if (std::strtod(buf, nullptr) == v) break;
+    }
+    std::string s(buf);
+    // Go switches to exponent form below 1e-6 and from 1e21; %g does so earlier: re-render plain decimals
+    double a = std::fabs(v);
+    if (a >= 1e-6 && a < 1e21 && s.find('e') != std::string::npos) {
+        for (int prec = 0; prec <= 30; prec++) {
+            std::snprintf(buf, sizeof buf, "%.*f", prec, v);
+            if (std::strtod(buf, nullptr) == v) break;
+        }
+        s = buf;
+    } else if (s.find('e') != std::string::npos) {
+        // Go writes e-07 as e-07 and e+21 as e+21 (two exponent digits minimum), same as C
+    }
+    return s;
+}
+
+void Writer::comma_and_indent() {
+    if (after_key_) { after_key_ = false; return; }
+    if (!counts_.empty()) {
+        if (counts_.back() > 0) out_ += ",";
+        counts_.back()++;
+        out_ += "\n";
+        out_.append(2 * counts_.size(), ' ');
+    }
+}
+void Writer::begin_object() { comma_and_indent(); out_ += "{"; counts_.push_back(0); }
+void Writer::end_object() {
+    int n = counts_.back();
+    counts_.pop_back();
+    if (n > 0) { out_ += "\n"; out_.append(2 * counts_.size(), ' '); }
+    out_ += "}";
+}
+void Writer::begin_array() { comma_and_indent(); out_ += "["; counts_.push_back(0); }
+void Writer::end_array() {
+    int n = counts_.back();
+    counts_.pop_back();
+    if (n > 0) { out_ += "\n"; out_.append(2 * counts_.size(), ' '); }
+    out_ += "]";
+}
+void Writer::raw_string(const std::string &v) {
+    out_ += '"';
+    for (unsigned char c : v) {
+        switch (c) {
+            case '"': out_ += "\\\""; break;
+            case '\\': out_ += "\\\\"; break;
+            case '\n': out_ += "\\n"; break;
+            case '\r': out_ += "\\r"; break;
+            case '\t': out_ += "\\t"; break;
+            case '<': out_ += "\\u003c"; break;  // encoding/json escapes HTML-sensitive characters by default
+            case '>': out_ += "\\u003e"; break;
+            case '&': out_ += "\\u0026"; break;
+            default:
+                if (c < 0x20) { char b[8]; std::snprintf(b, sizeof b, "\\u%04x", c); out_ += b; }
+                else out_ += (char)c;
+        }
+    }
+    out_ += '"';
+}
+void Writer::key(const std::string &k) {
+    comma_and_indent();
+    raw_string(k);
+    out_ += ": ";
+    after_key_ = true;
+}
+void Writer::value(double v) { comma_and_indent(); out_ += format_number(v); }
+void Writer::value(long long v) { comma_and_indent(); out_ += std::to_string(v); }
+void Writer::value(bool v) { comma_and_indent(); out_ += v ? "true" : "false"; }
+void Writer::null() { comma_and_indent(); out_ += "null"; }
+void Writer::value(const std::string &v) { comma_and_indent(); raw_string(v); }
+
+}  // namespace json
+}  // namespace pthost

@@ -1,0 +1,164 @@
+"""The C++ mirror of the Go host layer (csrc/host): scene JSON model, flattening, PNG, CLI flags.
+CPU only; the GPU leg of the CLI is in test_host_cpp_gpu.py."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENE_NAMES, scene_path
+
+
+@pytest.fixture(scope="module")
+def host():
+    from path_trace_golang_amd import build, capi
+
+    build.build_all()
+    L = C.CDLL(os.path.join(ROOT, "path_trace_golang_amd", "libpthost.so"))
+    L.pth_last_error.restype = C.c_char_p
+    L.pth_scene_load.restype = C.c_void_p
+    L.pth_scene_load.argtypes = [C.c_char_p]
+    L.pth_scene_decode.restype = C.c_void_p
+    L.pth_scene_decode.argtypes = [C.c_char_p]
+    L.pth_scene_free.argtypes = [C.c_void_p]
+    L.pth_scene_flat.restype = C.POINTER(capi.PtScene)
+    L.pth_scene_flat.argtypes = [C.c_void_p]
+    L.pth_scene_has_sky.argtypes = [C.c_void_p]
+    L.pth_scene_has_fog.argtypes = [C.c_void_p]
+    L.pth_scene_encode.restype = C.c_char_p
+    L.pth_scene_encode.argtypes = [C.c_void_p]
+    L.pth_scene_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.pth_settings_for_mode.argtypes = [C.c_char_p, C.POINTER(C.c_int32)]
+    L.pth_save_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.pth_render_into.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    return L
+
+
+def _same_flat(a, b):
+    assert a.num_materials == b.num_materials and a.num_objects == b.num_objects
+    for i in range(a.num_materials):
+        x, y = a.materials[i], b.materials[i]
+        assert (x.type, list(x.albedo), x.rough, x.ior, list(x.emit), x.power, list(x.absorption), x.smoothness) == \
+               (y.type, list(y.albedo), y.rough, y.ior, list(y.emit), y.power, list(y.absorption), y.smoothness)
+    for i in range(a.num_objects):
+        x, y = a.objects[i], b.objects[i]
+        assert (x.type, x.material, list(x.position), list(x.size)) == (y.type, y.material, list(y.position), list(y.size))
+    for f in ("position", "target", "up"):
+        assert list(getattr(a.camera, f)) == list(getattr(b.camera, f))
+    assert (a.camera.fov, a.camera.aperture, a.camera.focus_dist, a.camera.aspect_ratio) == \
+           (b.camera.fov, b.camera.aperture, b.camera.focus_dist, b.camera.aspect_ratio)
+    assert a.sky.kind == b.sky.kind
+    for f in ("background", "color", "horizon", "zenith"):
+        assert list(getattr(a.sky, f)) == list(getattr(b.sky, f))
+
+
+@pytest.mark.parametrize("name", SCENE_NAMES)
+def test_cpp_loader_equals_python_loader(host, name):
+    from path_trace_golang_amd import hip, scene
+
+    h = host.pth_scene_load(scene_path(name).encode())
+    assert h, host.pth_last_error()
+    try:
+        _same_flat(host.pth_scene_flat(h).contents, hip.FlatScene(scene.load(scene_path(name))).c)
+        # Save -> Load round trip is lossless and matches the Python writer's document
+        text = host.pth_scene_encode(h).decode()
+        assert text.startswith("{\n  \"name\"") and text.endswith("}\n")
+        assert json.loads(text) == scene.load(scene_path(name)).encode()
+        h2 = host.pth_scene_decode(text.encode())
+        _same_flat(host.pth_scene_flat(h2).contents, host.pth_scene_flat(h).contents)
+        host.pth_scene_free(h2)
+    finally:
+        host.pth_scene_free(h)
+
+
+def test_cpp_decoder_rules(host):
+    doc = {"NAME": "x", "camera": {"FOV": 12.5}, "sky": None, "objects": [{"type": "cube", "material_id": "q"}],
+           "materials": [{"id": "q", "type": "metal"}, {"id": "q", "type": "mirror", "rough": 1e-7}], "junk": [1, {"a": "é\n"}]}
+    h = host.pth_scene_decode(json.dumps(doc).encode())
+    assert h, host.pth_last_error()
+    f = host.pth_scene_flat(h).contents
+    assert f.camera.fov == 12.5 and host.pth_scene_has_sky(h) == 0 and host.pth_scene_has_fog(h) == 0
+    assert f.objects[0].type == -1 and f.objects[0].material == 1 and f.materials[1].rough == 1e-7
+    host.pth_scene_free(h)
+    assert not host.pth_scene_decode(b"{ \"a\": }") and b"decode scene" in host.pth_last_error()
+    assert not host.pth_scene_load(b"/nonexistent/s.json") and b"open scene" in host.pth_last_error()
+    assert not host.pth_scene_decode(b"[1,2]") and b"decode scene" in host.pth_last_error()
+
+
+def test_cpp_number_formatting_roundtrip(host):
+    vals = [0, 1, -1, 0.1, 1.7777778, 1e-7, 123456789.125, 2.5e21, -0.9520649081431036, 1e20, 5e-324, 255.999]
+    doc = {"materials": [{"id": "m", "rough": v} for v in vals]}
+    h = host.pth_scene_decode(json.dumps(doc).encode())
+    back = json.loads(host.pth_scene_encode(h).decode())
+    assert [m["rough"] for m in back["materials"]] == [float(v) for v in vals]
+    host.pth_scene_free(h)
+
+
+def test_settings_presets_and_backend_switch(host):
+    out = (C.c_int32 * 4)()
+    host.pth_settings_for_mode(b"final", out)
+    assert list(out) == [1920, 1080, 1000, 80]
+    host.pth_settings_for_mode(b"whatever", out)
+    assert list(out) == [400, 225, 20, 20]
+    host.pth_set_backend(0)
+    assert host.pth_get_backend() == 0
+    host.pth_set_backend(42)
+    assert host.pth_get_backend() == 0  # unknown -> CPU (backend.go:16-23)
+    h = host.pth_scene_load(scene_path("example_simple").encode())
+    buf = np.zeros((4, 4, 4), np.uint8)
+    rc = host.pth_render_into(h, 4, 4, 1, 1, 1, buf.ctypes.data_as(C.c_void_p), 4, 4, 16, None)
+    assert rc == 1 and b"BackendCPU" in host.pth_last_error()  # the CPU branch is not shipped: loud error
+    host.pth_set_backend(1)
+    assert host.pth_get_backend() == 1
+    host.pth_scene_free(h)
+
+
+def test_png_encoder(host, tmp_path):
+    from PIL import Image
+
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    img[..., 3] = 255
+    p = str(tmp_path / "a.png")
+    assert host.pth_save_png(p.encode(), img.ctypes.data_as(C.c_void_p), 53, 37, 53 * 4) == 0
+    im = Image.open(p)
+    assert im.mode == "RGB"  # opaque image.RGBA -> 8-bit truecolour, like Go's image/png
+    assert np.array_equal(np.array(im), img[..., :3])
+    img[5, 7, 3] = 9
+    assert host.pth_save_png(p.encode(), img.ctypes.data_as(C.c_void_p), 53, 37, 53 * 4) == 0
+    im = Image.open(p)
+    assert im.mode == "RGBA" and np.array_equal(np.array(im), img)
+    big = rng.integers(0, 256, (300, 200, 4), dtype=np.uint8)  # > 64 KiB: several stored deflate blocks
+    big[..., 3] = 255
+    assert host.pth_save_png(p.encode(), big.ctypes.data_as(C.c_void_p), 200, 300, 800) == 0
+    assert np.array_equal(np.array(Image.open(p)), big[..., :3])
+    assert host.pth_save_png(str(tmp_path / "no" / "a.png").encode(), big.ctypes.data_as(C.c_void_p), 200, 300, 800) == 1
+    assert b"create png" in host.pth_last_error()
+
+
+def _cli(*args):
+    exe = os.path.join(ROOT, "path_trace_golang_amd", "render")
+    return subprocess.run([exe, *args], capture_output=True, text=True, cwd=ROOT, timeout=120)
+
+
+def test_cli_flag_surface(host):
+    r = _cli("-nope")
+    assert r.returncode == 2 and "flag provided but not defined: -nope" in r.stderr and "Usage of render" in r.stderr
+    r = _cli("-scene")
+    assert r.returncode == 2 and "flag needs an argument: -scene" in r.stderr
+    r = _cli("-gpu=maybe")
+    assert r.returncode == 2 and "invalid boolean value" in r.stderr
+    r = _cli("-width", "x")
+    assert r.returncode == 2 and "invalid value" in r.stderr
+    r = _cli("-h")
+    assert r.returncode == 0 and "-headless" in r.stderr and "-mode string" in r.stderr
+    # defaults of cmd/render/main.go:17-21 are echoed by the flags log line
+    r = _cli("--headless=true", "-scene=/nonexistent.json", "-gpu")
+    assert r.returncode == 1 and "pathtracer: starting main()" in r.stderr
+    assert "flags: scene=/nonexistent.json mode=preview headless=true out=output.png" in r.stderr
+    assert "headless render error: load scene: open scene" in r.stderr
+    r = _cli()  # no -headless: the reference would open the UI
+    assert r.returncode == 1 and "ui error" in r.stderr
