@@ -234,6 +234,12 @@ int32_t pt_untile_device(pt_ctx *ctx, int32_t width, int32_t height, int32_t sha
  */
 int32_t pt_debug_profile(pt_ctx *ctx, uint64_t *out, int32_t n);
 
+/* Diagnostics only: with PTCORE_SCAN=verify at pt_create the trace kernel runs BOTH closest-hit
+ * strategies (the FP32-culled one and the plain every-object FP64 scan) for every segment, renders
+ * with the plain one and counts the segments on which the two disagree.  Returns that count,
+ * accumulated over every frame finished in this process (0 = the culling never changed a result). */
+int64_t pt_debug_scan_mismatches(pt_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

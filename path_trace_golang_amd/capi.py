@@ -95,6 +95,7 @@ SYMBOLS = [
     ("pt_untile_device", C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp,
                                       _vp]),
     ("pt_debug_profile", C.c_int32, [_vp, C.POINTER(C.c_uint64), C.c_int32]),
+    ("pt_debug_scan_mismatches", C.c_int64, [_vp]),
 ]
 
 

@@ -47,6 +47,24 @@ struct alignas(8) DevMat {
 };
 static_assert(sizeof(DevMat) == 104, "DevMat layout");
 
+// Broad-phase records (FP32, read with scalar loads): conservative bounds of the finite
+// objects, inflated by `m = 2^-12 * scene bound` and rounded outward, so that an FP32 test
+// can only ever keep too many candidates, never drop one the FP64 test would accept.
+struct alignas(16) BroadSphere {
+    float cx, cy, cz;
+    float rm2;         // (radius + m)^2, rounded up
+    int32_t index;     // object index = bit in the candidate mask
+    int32_t pad[3];
+};
+static_assert(sizeof(BroadSphere) == 32, "BroadSphere layout");
+struct alignas(16) BroadBox {
+    float lo[3];       // min - m, rounded down
+    float hi[3];       // max + m, rounded up
+    int32_t index;
+    int32_t pad;
+};
+static_assert(sizeof(BroadBox) == 32, "BroadBox layout");
+
 struct DevCamera {     // camera.go:9-17 after newCamera (camera.go:19-58)
     double origin[3];
     double lower_left[3];
@@ -76,6 +94,13 @@ struct DevFrame {
     uint32_t S;          // samples per pixel in the chunk
     uint32_t njobs;      // nlocal*16*S*64
     uint32_t claim;      // jobs a wave claims per queue pop (multiple of 64)
+    int32_t n_bsph, n_bbox, n_plane;  // broad-phase record counts; planes are always tested exactly
+    int32_t broad_ok;    // 1: nobj <= 64 and every finite object has finite bounds -> broad/narrow scan usable
+    uint64_t all_mask;   // bit i set for every object i
+    uint64_t diel_mask;  // objects whose material is dielectric
+    uint64_t sphere_mask, box_mask;
+    float origin_bound;  // rays whose origin leaves [-origin_bound, origin_bound]^3 keep every candidate
+    float pad_f;
     uint64_t seed_key;   // ptm::seed_key(seed)
     double inv_width;    // 1/(W-1)  renderer.go:95
     double inv_height;   // 1/(H-1)  renderer.go:96
@@ -85,6 +110,12 @@ struct DevFrame {
 struct TraceBuffers {
     const DevObj *objs;
     const DevMat *mats;
+    const BroadSphere *bsph;
+    const BroadBox *bbox;
+    const int32_t *plane_idx;
+    const double *ray;    // [6][njobs] primary rays of the chunk (raygen_kernel)
+    const unsigned long long *ray_rng;  // [njobs] stream state after the camera draws
+    const uint16_t *ray_ndraw;          // [njobs] draws used by ray generation; 0xffff = pixel outside the frame
     double *L;            // [3][njobs]
     uint32_t *job_seg;    // [njobs] or null (PT_FLAG_PIXEL_STATS)
     uint32_t *job_draw;   // [njobs] or null

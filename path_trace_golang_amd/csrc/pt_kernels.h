@@ -9,8 +9,14 @@
 //                   and Russian roulette (renderer.go:375-393) run in one loop whose
 //                   scan section is executed by all 64 lanes together: the exit search
 //                   of a glass hit is just that lane's next trip through the same scan.
-//                   The world is read with scalar loads (wave-uniform index) for the
-//                   scan and from an LDS copy for the per-lane winner look-up.
+//                   Two scan strategies produce the same winner bit for bit:
+//                     SCAN_UNIFORM  every lane tests every object in FP64 (wave-uniform index,
+//                                   scalar loads);
+//                     SCAN_BROAD    an FP32 broad phase over conservative (inflated) bounds
+//                                   builds a per-lane candidate bitmask, then each lane runs
+//                                   the exact FP64 tests only on its own candidates (per-lane
+//                                   look-ups in the LDS copy of the world).  Needs <= 64 objects.
+//                     SCAN_VERIFY   runs both and counts disagreements (diagnostics).
 //   resolve_kernel  per pixel slot, adds the chunk's sample radiances IN SAMPLE ORDER
 //                   to the running sum (renderer.go:186), and on request finishes the
 //                   pixel: 1/spp, sqrt gamma, *255.999, clamp, truncate (renderer.go:190-221).
@@ -78,15 +84,356 @@ __device__ __forceinline__ void reflect_vec(double vx, double vy, double vz, dou
     rz = vz - nz * 2 * dot;
 }
 
+
 // Section ids of the diagnostic build (PROF = true): per section the kernel counts wave
 // executions, active lanes and shader-clock cycles (leader lane only).  The shipping
 // instantiations have PROF = false and contain none of this.
 enum { SEC_ITER = 0, SEC_RAYGEN, SEC_LENS, SEC_SCAN, SEC_SPH_ROOT, SEC_SPH_ROOT2, SEC_HITREC, SEC_COSINE,
-       SEC_DIEL, SEC_EXITPOST, SEC_RR, SEC_FINISH, SEC_SKY, SEC_UNITDIR, SEC_COUNT };
+       SEC_DIEL, SEC_EXITPOST, SEC_RR, SEC_FINISH, SEC_SKY, SEC_UNITDIR, SEC_BROAD, SEC_NSPH, SEC_NBOX, SEC_PLANE, SEC_COUNT };
 
-template <bool STATS, bool PROF>
-__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const DevCamera cam, const DevSky sky,
-                                                           const TraceBuffers B) {
+
+enum { SCAN_UNIFORM = 0, SCAN_BROAD = 1, SCAN_VERIFY = 2 };
+
+// Diagnostic hooks handed to the scan routines (all no-ops unless PROF).
+struct ProfHooks {
+    uint32_t *exec;
+    uint32_t *lanes;
+    unsigned long long *cyc;
+    uint32_t lane;
+};
+#define PH_BEGIN(id)                                                              \
+    unsigned long long pht_##id = 0;                                              \
+    bool phl_##id = false;                                                        \
+    if (PROF) {                                                                   \
+        const uint64_t m_ = __ballot(1);                                          \
+        phl_##id = ph.lane == (uint32_t)(__ffsll((long long)m_) - 1);             \
+        ph.lanes[id]++;                                                           \
+        if (phl_##id) { ph.exec[id]++; pht_##id = __builtin_amdgcn_s_memtime(); } \
+    }
+#define PH_END(id) \
+    if (PROF && phl_##id) ph.cyc[id] += __builtin_amdgcn_s_memtime() - pht_##id;
+
+
+struct RayD {
+    double ox, oy, oz, dx, dy, dz;
+};
+
+// Exact sphere test, objects.go:37-61: first root (near, then far) that lies in [tmin, tmax].
+__device__ __forceinline__ bool sphere_exact(double cx, double cy, double cz, double radius_sq, const RayD &r, double a,
+                                             double tmin, double tmax, double &t) {
+    const double ocx = r.ox - cx, ocy = r.oy - cy, ocz = r.oz - cz;
+    const double halfB = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+    const double ocLenSq = ocx * ocx + ocy * ocy + ocz * ocz;
+    const double c = ocLenSq - radius_sq;
+    const double disc = halfB * halfB - a * c;
+    bool valid = false;
+    if (!(disc < 0)) {
+        const double sq = ptm::f_sqrt(disc);
+        double root = (-halfB - sq) / a;
+        valid = true;
+        if (root < tmin || root > tmax) {
+            root = (-halfB + sq) / a;
+            if (root < tmin || root > tmax) valid = false;
+        }
+        t = root;
+    }
+    return valid;
+}
+
+// Exact slab test, objects.go:141-179.  t0 only grows and t1 only shrinks, so the per-axis early
+// return of objects.go:176 equals the single test after the third axis.
+__device__ __forceinline__ bool box_exact(double ax, double ay, double az, double bx, double by, double bz, const RayD &r,
+                                          double ivx, double ivy, double ivz, double tmin, double tmax, double &t) {
+    double t0 = tmin, t1 = tmax;
+    double tn = (ax - r.ox) * ivx, tf = (bx - r.ox) * ivx;
+    if (ivx < 0) { const double s = tn; tn = tf; tf = s; }
+    if (tn > t0) t0 = tn;
+    if (tf < t1) t1 = tf;
+    tn = (ay - r.oy) * ivy; tf = (by - r.oy) * ivy;
+    if (ivy < 0) { const double s = tn; tn = tf; tf = s; }
+    if (tn > t0) t0 = tn;
+    if (tf < t1) t1 = tf;
+    tn = (az - r.oz) * ivz; tf = (bz - r.oz) * ivz;
+    if (ivz < 0) { const double s = tn; tn = tf; tf = s; }
+    if (tn > t0) t0 = tn;
+    if (tf < t1) t1 = tf;
+    t = t0;
+    return !(t1 <= t0);
+}
+
+// Exact plane test, objects.go:98-112.
+__device__ __forceinline__ bool plane_exact(double px, double py, double pz, double nx, double ny, double nz, const RayD &r,
+                                            double tmin, double tmax, double &t) {
+    const double denom = nx * r.dx + ny * r.dy + nz * r.dz;
+    if (ptm::f_abs(denom) < 1e-6) return false;
+    t = ((px - r.ox) * nx + (py - r.oy) * ny + (pz - r.oz) * nz) / denom;
+    return !(t < tmin || t > tmax);
+}
+
+// renderer.go:333-347 without the `t < exitT` part: glass back face at a sane distance from the
+// entry point (which is the ray origin during an exit search).
+template <typename ObjRef>
+__device__ __forceinline__ bool exit_candidate_ok(const ObjRef &o, int kind, const RayD &r, double t) {
+    const double px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
+    double nx, ny, nz;
+    outward_normal(o, kind, px, py, pz, nx, ny, nz);
+    const bool ff = (r.dx * nx + r.dy * ny + r.dz * nz) < 0;
+    if (ff) return false;
+    const double ex = px - r.ox, ey = py - r.oy, ez = pz - r.oz;
+    const double distSq = ex * ex + ey * ey + ez * ez;
+    return distSq > 1e-8 && distSq < 1000.0;
+}
+
+// The reference's closest-hit loop (renderer.go:297-302) and exit search (renderer.go:329-349),
+// object by object in file order, every lane on the same object.
+template <typename ObjPtr>
+__device__ __forceinline__ void scan_uniform(const DevFrame &F, ObjPtr g_obj, const RayD &r, int mode, int &best,
+                                             double &tmax) {
+    const double tmin = mode ? 0.0001 : 0.001;  // renderer.go:322 / :292
+    tmax = ptm::max_float64();
+    best = -1;
+    const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;      // objects.go:43, same for every sphere
+    const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;  // objects.go:149,154,159
+    for (int i = 0; i < F.nobj; i++) {
+        const auto &o = g_obj[i];
+        const int kind = o.kind & 0xff;
+        const bool diel = (o.kind & 0x100) != 0;
+        if (mode != 0 && !diel) continue;  // only glass can end an exit search (renderer.go:333)
+        bool valid;
+        double t = 0;
+        if (kind == KIND_SPHERE) valid = sphere_exact(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, tmin, tmax, t);
+        else if (kind == KIND_BOX) valid = box_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, tmax, t);
+        else valid = plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t);
+        if (valid) {
+            if (mode == 0) {
+                best = i;
+                tmax = t;
+            } else if (t < tmax && exit_candidate_ok(o, kind, r, t)) {
+                best = i;
+                tmax = t;
+            }
+        }
+    }
+}
+
+// Order-free statement of the sequential winner.  Closest-hit mode: smallest t; on an exact tie a
+// sphere/plane beats a box (their range test is inclusive, objects.go:56-60, :110, the box's is
+// exclusive, :176), among spheres/planes the higher index wins, among boxes the lower.  Exit mode:
+// smallest t, lower index on a tie (`tempRec.t < exitT`, renderer.go:333).
+__device__ __forceinline__ bool wins(int mode, bool is_box, int i, double t, int best, bool best_is_box, double tmax) {
+    if (t < tmax) return true;
+    if (!(t == tmax)) return false;
+    if (best < 0) return !is_box;  // tmax is still MaxFloat64: inclusive tests accept t == MaxFloat64, the box does not
+    if (mode != 0) return i < best;
+    if (is_box) return false;
+    return best_is_box || i > best;
+}
+
+// Broad phase in FP32 over inflated bounds + exact FP64 narrow phase over the survivors.
+template <bool PROF, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
+__device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_obj, SphPtr g_bs, BoxPtr g_bb, IdxPtr g_pl,
+                                                  const DevObj *s_obj, const RayD &r, int mode, int &best, double &tmax,
+                                                  const ProfHooks &ph) {
+    const double tmin = mode ? 0.0001 : 0.001;
+    tmax = ptm::max_float64();
+    best = -1;
+    bool best_is_box = false;
+    const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+
+    // ---- planes: infinite, always tested exactly (wave-uniform, scalar loads)
+    PH_BEGIN(SEC_PLANE)
+    for (int k = 0; k < F.n_plane; k++) {
+        const int i = g_pl[k];
+        const auto &o = g_obj[i];
+        if (mode != 0 && !(o.kind & 0x100)) continue;
+        double t = 0;
+        if (plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t)) {
+            if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
+                          : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_PLANE, r, t))) {
+                best = i;
+                tmax = t;
+                best_is_box = false;
+            }
+        }
+    }
+
+    PH_END(SEC_PLANE)
+    // ---- broad phase
+    PH_BEGIN(SEC_BROAD)
+    const float fox = (float)r.ox, foy = (float)r.oy, foz = (float)r.oz;
+    const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
+    const float fa = __builtin_fmaf(fdx, fdx, __builtin_fmaf(fdy, fdy, fdz * fdz));
+    // written so that NaN lands on "keep everything"
+    const bool trust = (fa > 1e-30f) && (fa < 1e30f) && (__builtin_fabsf(fox) <= F.origin_bound) &&
+                       (__builtin_fabsf(foy) <= F.origin_bound) && (__builtin_fabsf(foz) <= F.origin_bound);
+    const float tminf = mode ? 9.9e-5f : 9.9e-4f;  // a little below tMin
+    const float inv_a = __builtin_amdgcn_rcpf(fa);
+    uint32_t clo = 0, chi = 0;
+    for (int k = 0; k < F.n_bsph; k++) {
+        const auto &s = g_bs[k];
+        const float ocx = fox - s.cx, ocy = foy - s.cy, ocz = foz - s.cz;
+        const float b = __builtin_fmaf(ocx, fdx, __builtin_fmaf(ocy, fdy, ocz * fdz));
+        const float tca = -b * inv_a;  // parameter of closest approach
+        const float qx = __builtin_fmaf(fdx, tca, ocx), qy = __builtin_fmaf(fdy, tca, ocy), qz = __builtin_fmaf(fdz, tca, ocz);
+        const float d2 = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
+        const float rem = s.rm2 - d2;  // >= 0: the line passes within the inflated radius
+        const float u = tminf - tca;   // > 0: closest approach lies before tMin
+        const bool miss = (rem < 0.0f) || ((u > 0.0f) && (u * u * fa > rem));  // outside, or wholly behind
+        const uint32_t bit = 1u << (s.index & 31);
+        if (s.index < 32) clo |= miss ? 0u : bit;
+        else chi |= miss ? 0u : bit;
+    }
+    const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
+    for (int k = 0; k < F.n_bbox; k++) {
+        const auto &bx = g_bb[k];
+        const float tax = (bx.lo[0] - fox) * ivxf, tbx = (bx.hi[0] - fox) * ivxf;
+        const float tay = (bx.lo[1] - foy) * ivyf, tby = (bx.hi[1] - foy) * ivyf;
+        const float taz = (bx.lo[2] - foz) * ivzf, tbz = (bx.hi[2] - foz) * ivzf;
+        // v_min/v_max return the other operand for a NaN: a NaN slab (0 * inf) constrains nothing
+        const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)),
+                                         __builtin_fmaxf(__builtin_fminf(taz, tbz), tminf));
+        const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
+                                         __builtin_fmaxf(taz, tbz));
+        const bool miss = t1 < t0;
+        const uint32_t bit = 1u << (bx.index & 31);
+        if (bx.index < 32) clo |= miss ? 0u : bit;
+        else chi |= miss ? 0u : bit;
+    }
+    uint64_t cand = ((uint64_t)chi << 32) | clo;
+    if (!trust) cand = F.sphere_mask | F.box_mask;
+    if (mode != 0) cand &= F.diel_mask;
+    PH_END(SEC_BROAD)
+
+    // ---- narrow phase: spheres, then boxes, each lane on its own candidates (index order)
+    uint64_t ms = cand & F.sphere_mask;
+    while (__ballot(ms != 0) != 0) {
+        if (ms != 0) {
+            PH_BEGIN(SEC_NSPH)
+            const int i = __builtin_ctzll(ms);
+            ms &= ms - 1;
+            const DevObj &o = s_obj[i];
+            double t = 0;
+            if (sphere_exact(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, tmin, tmax, t)) {
+                if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
+                              : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_SPHERE, r, t))) {
+                    best = i;
+                    tmax = t;
+                    best_is_box = false;
+                }
+            }
+            PH_END(SEC_NSPH)
+        }
+    }
+    uint64_t mb = cand & F.box_mask;
+    if (__ballot(mb != 0) != 0) {
+        const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
+        while (__ballot(mb != 0) != 0) {
+            if (mb != 0) {
+                PH_BEGIN(SEC_NBOX)
+                const int i = __builtin_ctzll(mb);
+                mb &= mb - 1;
+                const DevObj &o = s_obj[i];
+                double t = 0;
+                // the range is left open at the top here: `wins` compares t with tmax (strictly for a box)
+                if (box_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t)) {
+                    if (mode == 0 ? wins(0, true, i, t, best, best_is_box, tmax)
+                                  : (wins(1, true, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_BOX, r, t))) {
+                        best = i;
+                        tmax = t;
+                        best_is_box = true;
+                    }
+                }
+                PH_END(SEC_NBOX)
+            }
+        }
+    }
+}
+
+// Ray generation pre-pass: one thread per job of the chunk, all lanes busy and neighbouring
+// lanes on neighbouring pixels.  Per job: stream init, u then v (renderer.go:182-183),
+// camera.getRay with the lens rejection loop (camera.go:60-74, math.go:74-84).  Writes the primary
+// ray (6 doubles, SoA), the stream state after the draws, and the number of draws used (0xffff marks a
+// job whose pixel lies outside the frame).
+__global__ __launch_bounds__(PT_BLOCK) void raygen_kernel(const DevFrame F, const DevCamera cam, double *__restrict__ ray,
+                                                            unsigned long long *__restrict__ ray_rng,
+                                                            uint16_t *__restrict__ ray_ndraw) {
+    const uint32_t myjob = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (myjob >= F.njobs) return;
+    // job -> (tile, sub-block, sample, pixel)
+    const uint32_t p = myjob & 63u;
+    const uint32_t q = myjob >> 6;
+    const uint32_t blk = q / F.S;
+    const uint32_t sl = q - blk * F.S;
+    const uint32_t lt = blk >> 4, sb = blk & 15u;
+    const uint32_t t = (uint32_t)F.shard_index + lt * (uint32_t)F.shard_count;
+    const uint32_t ty = t / (uint32_t)F.ntx, tx = t - ty * (uint32_t)F.ntx;
+    const uint32_t x = tx * 32u + (sb & 3u) * 8u + (p & 7u);
+    const uint32_t y = ty * 32u + (sb >> 2) * 8u + (p >> 3);
+    if (!(x < (uint32_t)F.width && y < (uint32_t)F.height)) {
+        ray_ndraw[myjob] = 0xffffu;
+        return;
+    }
+    uint32_t nd = 0;
+    const uint64_t pixel = (uint64_t)y * (uint64_t)(uint32_t)F.width + (uint64_t)x;
+    uint64_t rs = ptm::stream_init(F.seed_key, pixel, (uint64_t)(F.s0 + sl));
+#define RG_DRAW(var) const double var = ptm::stream_next(rs); nd++;
+    RG_DRAW(xi_u)
+    RG_DRAW(xi_v)
+    const double u = ((double)x + xi_u) * F.inv_width;
+    const double vv = ((F.height_m1 - (double)y) + xi_v) * F.inv_height;
+    const double tx_ = cam.lower_left[0] + cam.horizontal[0] * u;
+    const double ty_ = cam.lower_left[1] + cam.horizontal[1] * u;
+    const double tz_ = cam.lower_left[2] + cam.horizontal[2] * u;
+    const double ax = tx_ + cam.vertical[0] * vv;
+    const double ay = ty_ + cam.vertical[1] * vv;
+    const double az = tz_ + cam.vertical[2] * vv;
+    double ox, oy, oz, dx, dy, dz;
+    if (cam.lens_radius > 0) {
+        double rx, ry, rz;
+        for (;;) {  // randomInUnitSphere
+            RG_DRAW(d0)
+            RG_DRAW(d1)
+            RG_DRAW(d2)
+            rx = d0 * 2 - 1;
+            ry = d1 * 2 - 1;
+            rz = d2 * 2 - 1;
+            const double lenSq = rx * rx + ry * ry + rz * rz;
+            if (lenSq >= 1.0) continue;
+            break;
+        }
+        rx = rx * cam.lens_radius;
+        ry = ry * cam.lens_radius;
+        const double offx = cam.u[0] * rx + cam.v[0] * ry;
+        const double offy = cam.u[1] * rx + cam.v[1] * ry;
+        const double offz = cam.u[2] * rx + cam.v[2] * ry;
+        ox = cam.origin[0] + offx;
+        oy = cam.origin[1] + offy;
+        oz = cam.origin[2] + offz;
+        dx = (ax - cam.origin[0]) - offx;
+        dy = (ay - cam.origin[1]) - offy;
+        dz = (az - cam.origin[2]) - offz;
+    } else {
+        ox = cam.origin[0];
+        oy = cam.origin[1];
+        oz = cam.origin[2];
+        dx = ax - cam.origin[0];
+        dy = ay - cam.origin[1];
+        dz = az - cam.origin[2];
+    }
+#undef RG_DRAW
+    const size_t nj = F.njobs;
+    ray[myjob] = ox;
+    ray[nj + myjob] = oy;
+    ray[2 * nj + myjob] = oz;
+    ray[3 * nj + myjob] = dx;
+    ray[4 * nj + myjob] = dy;
+    ray[5 * nj + myjob] = dz;
+    ray_rng[myjob] = rs;
+    ray_ndraw[myjob] = (uint16_t)(nd < 0xfffeu ? nd : 0xfffeu);
+}
+
+template <bool STATS, bool PROF, int SCAN>
+__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const DevSky sky, const TraceBuffers B) {
     extern __shared__ __align__(16) unsigned char smem[];
     DevObj *s_obj = reinterpret_cast<DevObj *>(smem);
     DevMat *s_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
@@ -107,6 +454,12 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
     // space so the wave-uniform scan index turns into scalar (SGPR) loads.
     typedef const DevObj __attribute__((address_space(4))) *ConstObjPtr;
     const ConstObjPtr g_obj = (ConstObjPtr)(B.objs);
+    typedef const BroadSphere __attribute__((address_space(4))) *ConstSphPtr;
+    typedef const BroadBox __attribute__((address_space(4))) *ConstBoxPtr;
+    typedef const int32_t __attribute__((address_space(4))) *ConstIdxPtr;
+    const ConstSphPtr g_bs = (ConstSphPtr)(B.bsph);
+    const ConstBoxPtr g_bb = (ConstBoxPtr)(B.bbox);
+    const ConstIdxPtr g_pl = (ConstIdxPtr)(B.plane_idx);
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
 
     // per-lane path state
@@ -120,6 +473,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
     double Tx = 1, Ty = 1, Tz = 1;
     uint32_t c_seg = 0, c_exit = 0, c_draw = 0, c_samples = 0;
     uint32_t j_seg = 0, j_draw = 0;
+    uint32_t c_mismatch = 0;  // SCAN_VERIFY only
 
     // wave-uniform job cursor
     uint32_t cur = 0, end = 0;
@@ -173,17 +527,9 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             cur += nneed < avail ? nneed : avail;
 
             if (take) {
-                // job -> (tile, sub-block, sample, pixel)
-                const uint32_t p = myjob & 63u;
-                const uint32_t q = myjob >> 6;
-                const uint32_t blk = q / F.S;
-                const uint32_t sl = q - blk * F.S;
-                const uint32_t lt = blk >> 4, sb = blk & 15u;
-                const uint32_t t = (uint32_t)F.shard_index + lt * (uint32_t)F.shard_count;
-                const uint32_t ty = t / (uint32_t)F.ntx, tx = t - ty * (uint32_t)F.ntx;
-                const uint32_t x = tx * 32u + (sb & 3u) * 8u + (p & 7u);
-                const uint32_t y = ty * 32u + (sb >> 2) * 8u + (p >> 3);
-                if (x < (uint32_t)F.width && y < (uint32_t)F.height) {
+                // the primary ray of this job was generated by raygen_kernel (coherent pre-pass)
+                const uint32_t nd = B.ray_ndraw[myjob];
+                if (nd != 0xffffu) {  // 0xffff: the job's pixel lies outside the frame (edge tile)
                     SEC_BEGIN(SEC_RAYGEN)
                     job = myjob;
                     active = true;
@@ -191,55 +537,16 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     depth = F.max_depth;
                     Tx = 1; Ty = 1; Tz = 1;
                     c_samples++;
-                    if (STATS) { j_seg = 0; j_draw = 0; }
-                    const uint64_t pixel = (uint64_t)y * (uint64_t)(uint32_t)F.width + (uint64_t)x;
-                    rs = ptm::stream_init(F.seed_key, pixel, (uint64_t)(F.s0 + sl));
-                    // renderer.go:182-183: u first, then v
-                    PT_DRAW(xi_u)
-                    PT_DRAW(xi_v)
-                    const double u = ((double)x + xi_u) * F.inv_width;
-                    const double vv = ((F.height_m1 - (double)y) + xi_v) * F.inv_height;
-                    // camera.getRay, camera.go:60-74
-                    const double tx_ = cam.lower_left[0] + cam.horizontal[0] * u;
-                    const double ty_ = cam.lower_left[1] + cam.horizontal[1] * u;
-                    const double tz_ = cam.lower_left[2] + cam.horizontal[2] * u;
-                    const double ax = tx_ + cam.vertical[0] * vv;
-                    const double ay = ty_ + cam.vertical[1] * vv;
-                    const double az = tz_ + cam.vertical[2] * vv;
-                    if (cam.lens_radius > 0) {
-                        double rx, ry, rz;
-                        for (;;) {  // randomInUnitSphere, math.go:74-84
-                            SEC_BEGIN(SEC_LENS)
-                            PT_DRAW(d0)
-                            PT_DRAW(d1)
-                            PT_DRAW(d2)
-                            rx = d0 * 2 - 1;
-                            ry = d1 * 2 - 1;
-                            rz = d2 * 2 - 1;
-                            const double lenSq = rx * rx + ry * ry + rz * rz;
-                            SEC_END(SEC_LENS)
-                            if (lenSq >= 1.0) continue;
-                            break;
-                        }
-                        rx = rx * cam.lens_radius;
-                        ry = ry * cam.lens_radius;
-                        const double offx = cam.u[0] * rx + cam.v[0] * ry;
-                        const double offy = cam.u[1] * rx + cam.v[1] * ry;
-                        const double offz = cam.u[2] * rx + cam.v[2] * ry;
-                        ox = cam.origin[0] + offx;
-                        oy = cam.origin[1] + offy;
-                        oz = cam.origin[2] + offz;
-                        dx = (ax - cam.origin[0]) - offx;
-                        dy = (ay - cam.origin[1]) - offy;
-                        dz = (az - cam.origin[2]) - offz;
-                    } else {
-                        ox = cam.origin[0];
-                        oy = cam.origin[1];
-                        oz = cam.origin[2];
-                        dx = ax - cam.origin[0];
-                        dy = ay - cam.origin[1];
-                        dz = az - cam.origin[2];
-                    }
+                    c_draw += nd;
+                    if (STATS) { j_seg = 0; j_draw = nd; }
+                    const size_t nj = F.njobs;
+                    ox = B.ray[myjob];
+                    oy = B.ray[nj + myjob];
+                    oz = B.ray[2 * nj + myjob];
+                    dx = B.ray[3 * nj + myjob];
+                    dy = B.ray[4 * nj + myjob];
+                    dz = B.ray[5 * nj + myjob];
+                    rs = B.ray_rng[myjob];
                     SEC_END(SEC_RAYGEN)
                 }
             }
@@ -252,86 +559,32 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         if (active) {
             // -------------------------------------------------------- scan
             SEC_BEGIN(SEC_SCAN)
-            const double tmin = mode ? 0.0001 : 0.001;  // renderer.go:322 / :292
-            double tmax = ptm::max_float64();
-            int best = -1;
-            const double a = dx * dx + dy * dy + dz * dz;  // objects.go:43, same for every sphere
-            const double ivx = 1 / dx, ivy = 1 / dy, ivz = 1 / dz;  // objects.go:149,154,159
-
-            for (int i = 0; i < F.nobj; i++) {
-                const auto &o = g_obj[i];
-                const int kind = o.kind & 0xff;
-                const bool diel = (o.kind & 0x100) != 0;
-                if (mode != 0 && !diel) continue;  // only glass can end an exit search (renderer.go:333)
-                bool valid = false;
-                double t = 0;
-                if (kind == KIND_SPHERE) {  // objects.go:37-61
-                    const double ocx = ox - o.a[0], ocy = oy - o.a[1], ocz = oz - o.a[2];
-                    const double halfB = ocx * dx + ocy * dy + ocz * dz;
-                    const double ocLenSq = ocx * ocx + ocy * ocy + ocz * ocz;
-                    const double c = ocLenSq - o.radius_sq;
-                    const double disc = halfB * halfB - a * c;
-                    if (!(disc < 0)) {
-                        SEC_BEGIN(SEC_SPH_ROOT)
-                        const double sq = ptm::f_sqrt(disc);
-                        double root = (-halfB - sq) / a;
-                        valid = true;
-                        if (root < tmin || root > tmax) {
-                            SEC_BEGIN(SEC_SPH_ROOT2)
-                            root = (-halfB + sq) / a;
-                            if (root < tmin || root > tmax) valid = false;
-                            SEC_END(SEC_SPH_ROOT2)
-                        }
-                        t = root;
-                        SEC_END(SEC_SPH_ROOT)
-                    }
-                } else if (kind == KIND_BOX) {  // objects.go:141-179
-                    double t0 = tmin, t1 = tmax;
-                    double tn = (o.a[0] - ox) * ivx, tf = (o.b[0] - ox) * ivx;
-                    if (ivx < 0) { const double s = tn; tn = tf; tf = s; }
-                    if (tn > t0) t0 = tn;
-                    if (tf < t1) t1 = tf;
-                    tn = (o.a[1] - oy) * ivy; tf = (o.b[1] - oy) * ivy;
-                    if (ivy < 0) { const double s = tn; tn = tf; tf = s; }
-                    if (tn > t0) t0 = tn;
-                    if (tf < t1) t1 = tf;
-                    tn = (o.a[2] - oz) * ivz; tf = (o.b[2] - oz) * ivz;
-                    if (ivz < 0) { const double s = tn; tn = tf; tf = s; }
-                    if (tn > t0) t0 = tn;
-                    if (tf < t1) t1 = tf;
-                    // t0 only grows and t1 only shrinks, so the per-axis early return of
-                    // objects.go:176 equals this single test after the third axis
-                    valid = !(t1 <= t0);
-                    t = t0;
-                } else {  // plane, objects.go:98-112
-                    const double denom = o.b[0] * dx + o.b[1] * dy + o.b[2] * dz;
-                    if (!(ptm::f_abs(denom) < 1e-6)) {
-                        t = ((o.a[0] - ox) * o.b[0] + (o.a[1] - oy) * o.b[1] + (o.a[2] - oz) * o.b[2]) / denom;
-                        valid = !(t < tmin || t > tmax);
-                    }
-                }
-                if (valid) {
-                    if (mode == 0) {
-                        best = i;
-                        tmax = t;
-                    } else {
-                        // renderer.go:331-347: back face of glass, strictly nearer, sane distance
-                        const double px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;
-                        double nx, ny, nz;
-                        outward_normal(o, kind, px, py, pz, nx, ny, nz);
-                        const bool ff = (dx * nx + dy * ny + dz * nz) < 0;
-                        if (!ff && t < tmax) {
-                            const double ex = px - ox, ey = py - oy, ez = pz - oz;
-                            const double distSq = ex * ex + ey * ey + ez * ez;
-                            if (distSq > 1e-8 && distSq < 1000.0) {
-                                best = i;
-                                tmax = t;
-                            }
-                        }
-                    }
-                }
+            const RayD ray{ox, oy, oz, dx, dy, dz};
+            const ProfHooks ph{p_exec, p_lanes, p_cyc, lane};
+            int best;
+            double tmax;
+            if (SCAN == SCAN_UNIFORM) {
+                scan_uniform(F, g_obj, ray, mode, best, tmax);
+            } else if (SCAN == SCAN_BROAD) {
+                // The order-free winner rule assumes every candidate t is a number.  Rays with
+                // non-finite or absurd components (e.g. a 1-pixel-wide frame divides by W-1 = 0,
+                // renderer.go:95) can produce NaN roots, and those follow the sequential loop's
+                // NaN behaviour only in the sequential loop: such waves take the plain scan.
+                const double a_ = dx * dx + dy * dy + dz * dz;
+                const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
+                                  (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100);
+                if (__ballot(!tame) != 0) scan_uniform(F, g_obj, ray, mode, best, tmax);
+                else scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, ray, mode, best, tmax, ph);
+            } else {
+                int best2;
+                double tmax2;
+                scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, ray, mode, best2, tmax2, ph);
+                scan_uniform(F, g_obj, ray, mode, best, tmax);
+                const double a_ = dx * dx + dy * dy + dz * dz;
+                const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
+                                  (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100);
+                if (tame && (best != best2 || (best >= 0 && !(tmax == tmax2)))) c_mismatch++;
             }
-
             SEC_END(SEC_SCAN)
             // -------------------------------------------------------- shade
             bool do_rr = false;
@@ -587,6 +840,10 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         atomicAdd(&B.counters[1], (unsigned long long)w_exit);
         atomicAdd(&B.counters[2], (unsigned long long)w_draw);
         atomicAdd(&B.counters[3], (unsigned long long)w_samples);
+    }
+    if (SCAN == SCAN_VERIFY) {
+        const uint32_t w_mis = wave_sum(c_mismatch);
+        if (lane == 0 && w_mis) atomicAdd(&B.counters[4], (unsigned long long)w_mis);
     }
 }
 

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +32,7 @@ namespace {
 
 thread_local std::string g_last_error;
 unsigned long long g_profile_scratch[3 * ptk::SEC_COUNT] = {};
+unsigned long long g_mismatches = 0;  // SCAN_VERIFY disagreements of the last collected frame
 
 int32_t fail(int32_t code, const std::string &msg) {
     g_last_error = msg;
@@ -76,7 +78,13 @@ struct Device {
     hipStream_t stream = nullptr;  // own_stream or the caller's
     DevBuf<DevObj> objs;
     DevBuf<DevMat> mats;
+    DevBuf<BroadSphere> bsph;
+    DevBuf<BroadBox> bbox;
+    DevBuf<int32_t> plane_idx;
     DevBuf<double> L;
+    DevBuf<double> ray;
+    DevBuf<unsigned long long> ray_rng;
+    DevBuf<uint16_t> ray_ndraw;
     DevBuf<uint32_t> job_seg, job_draw;
     DevBuf<double> acc;
     DevBuf<uint32_t> acc_seg, acc_draw;
@@ -109,6 +117,10 @@ struct Frame {
     int32_t done_spp = 0;
     uint32_t chunk = 0;
     bool stats_on = false;
+    std::vector<BroadSphere> bsph;
+    std::vector<BroadBox> bbox;
+    std::vector<int32_t> plane_idx;
+    int scan = 0;  // ptk::SCAN_* used for this frame
     std::chrono::steady_clock::time_point t0;
 };
 
@@ -124,9 +136,11 @@ struct pt_ctx {
     DevBuf<uint8_t> f_rgba;
     DevBuf<double> f_accum;
     DevBuf<uint32_t> f_seg, f_draw;
-    size_t l_budget_bytes = (size_t)2 << 30;
+    size_t l_budget_bytes = (size_t)6 << 30;  // per-chunk job buffers (radiance + primary rays)
     uint32_t claim = 256;
     int max_blocks_per_cu = 8;
+    int scan_mode = ptk::SCAN_BROAD;  // PTCORE_SCAN=uniform|broad|verify
+    unsigned long long last_mismatches = 0;
     bool profile_sections = false;  // PTCORE_PROFILE=1: diagnostic kernel build with per-section counters
     unsigned long long last_profile[3 * ptk::SEC_COUNT] = {};
 };
@@ -277,6 +291,77 @@ DevSky make_sky(const pt_sky &s) {  // renderer.go:56-92
     return d;
 }
 
+float round_up_f(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+float round_down_f(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+
+// Conservative FP32 bounds for the broad phase.  B bounds every finite object's coordinates;
+// everything is inflated by m = B * 2^-12 (two orders of magnitude above the worst FP32 rounding of
+// the broad-phase arithmetic for ray origins inside [-4B, 4B]^3), and rounded outward.
+void build_broad(const std::vector<DevObj> &world, Frame &fr) {
+    DevFrame &F = fr.F;
+    fr.bsph.clear();
+    fr.bbox.clear();
+    fr.plane_idx.clear();
+    F.all_mask = F.diel_mask = F.sphere_mask = F.box_mask = 0;
+    double B = 1.0;
+    for (const DevObj &o : world) {
+        const int kind = o.kind & 0xff;
+        if (kind == KIND_SPHERE) {
+            for (int k = 0; k < 3; k++) B = std::max(B, std::fabs(o.a[k]) + std::fabs(o.radius));
+        } else if (kind == KIND_BOX) {
+            for (int k = 0; k < 3; k++) B = std::max(B, std::max(std::fabs(o.a[k]), std::fabs(o.b[k])));
+        }
+    }
+    if (!(B < 1e30)) B = INFINITY;  // absurd or non-finite geometry: every object stays a candidate
+    const double m = B * (1.0 / 4096.0);
+    for (size_t i = 0; i < world.size(); i++) {
+        const DevObj &o = world[i];
+        const int kind = o.kind & 0xff;
+        if (i < 64) {
+            const uint64_t bit = 1ull << i;
+            F.all_mask |= bit;
+            if (o.kind & 0x100) F.diel_mask |= bit;
+            if (kind == KIND_SPHERE) F.sphere_mask |= bit;
+            if (kind == KIND_BOX) F.box_mask |= bit;
+        }
+        if (kind == KIND_SPHERE) {
+            BroadSphere s;
+            std::memset(&s, 0, sizeof s);
+            s.cx = (float)o.a[0]; s.cy = (float)o.a[1]; s.cz = (float)o.a[2];
+            const double rm = std::fabs(o.radius) + m;
+            s.rm2 = round_up_f(rm * rm);
+            if (!(s.rm2 == s.rm2)) s.rm2 = INFINITY;
+            s.index = (int32_t)i;
+            fr.bsph.push_back(s);
+        } else if (kind == KIND_BOX) {
+            BroadBox b;
+            std::memset(&b, 0, sizeof b);
+            for (int k = 0; k < 3; k++) {
+                const double lo = std::min(o.a[k], o.b[k]) - m, hi = std::max(o.a[k], o.b[k]) + m;
+                b.lo[k] = (lo == lo) ? round_down_f(lo) : -INFINITY;
+                b.hi[k] = (hi == hi) ? round_up_f(hi) : INFINITY;
+            }
+            b.index = (int32_t)i;
+            fr.bbox.push_back(b);
+        } else {
+            fr.plane_idx.push_back((int32_t)i);
+        }
+    }
+    F.n_bsph = (int32_t)fr.bsph.size();
+    F.n_bbox = (int32_t)fr.bbox.size();
+    F.n_plane = (int32_t)fr.plane_idx.size();
+    F.broad_ok = world.size() <= 64 ? 1 : 0;
+    F.origin_bound = (float)std::min(4.0 * B, 3.0e38);
+}
+
 int32_t tiles_of_shard(int32_t ntiles, const pt_shard &sh) {
     if (sh.index >= ntiles) return 0;
     return (ntiles - sh.index + sh.count - 1) / sh.count;
@@ -294,6 +379,19 @@ int32_t validate(const pt_scene *scene, const pt_config *cfg) {
 }
 
 // ---------------------------------------------------------------- per-device frame
+
+using TraceFn = void (*)(const DevFrame, const DevSky, const TraceBuffers);
+
+// The shipping instantiations are <false,false,*>; STATS adds per-pixel counters, PROF the section profile.
+TraceFn pick_trace(bool stats, bool prof, int scan) {
+    if (prof) return scan == ptk::SCAN_UNIFORM ? ptk::trace_kernel<false, true, ptk::SCAN_UNIFORM>
+                                                : ptk::trace_kernel<false, true, ptk::SCAN_BROAD>;
+    if (scan == ptk::SCAN_VERIFY) return stats ? ptk::trace_kernel<true, false, ptk::SCAN_VERIFY>
+                                                : ptk::trace_kernel<false, false, ptk::SCAN_VERIFY>;
+    if (scan == ptk::SCAN_BROAD) return stats ? ptk::trace_kernel<true, false, ptk::SCAN_BROAD>
+                                               : ptk::trace_kernel<false, false, ptk::SCAN_BROAD>;
+    return stats ? ptk::trace_kernel<true, false, ptk::SCAN_UNIFORM> : ptk::trace_kernel<false, false, ptk::SCAN_UNIFORM>;
+}
 
 int32_t dev_events(Device &d, std::vector<EventPair> &v, size_t need) {
     while (v.size() < need) {
@@ -322,11 +420,20 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, cons
     if (!world.empty())
         HIP_TRY(hipMemcpyAsync(d.objs.p, world.data(), world.size() * sizeof(DevObj), hipMemcpyHostToDevice, d.stream));
     HIP_TRY(hipMemcpyAsync(d.mats.p, mats.data(), mats.size() * sizeof(DevMat), hipMemcpyHostToDevice, d.stream));
+    HIP_TRY(d.bsph.reserve(std::max<size_t>(1, fr.bsph.size())));
+    HIP_TRY(d.bbox.reserve(std::max<size_t>(1, fr.bbox.size())));
+    HIP_TRY(d.plane_idx.reserve(std::max<size_t>(1, fr.plane_idx.size())));
+    if (!fr.bsph.empty())
+        HIP_TRY(hipMemcpyAsync(d.bsph.p, fr.bsph.data(), fr.bsph.size() * sizeof(BroadSphere), hipMemcpyHostToDevice, d.stream));
+    if (!fr.bbox.empty())
+        HIP_TRY(hipMemcpyAsync(d.bbox.p, fr.bbox.data(), fr.bbox.size() * sizeof(BroadBox), hipMemcpyHostToDevice, d.stream));
+    if (!fr.plane_idx.empty())
+        HIP_TRY(hipMemcpyAsync(d.plane_idx.p, fr.plane_idx.data(), fr.plane_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
     // the copies above read pageable host vectors that die with the caller's scope
     HIP_TRY(hipStreamSynchronize(d.stream));
     HIP_TRY(d.queue.reserve(1));
-    HIP_TRY(d.counters.reserve(4));
-    HIP_TRY(hipMemsetAsync(d.counters.p, 0, 4 * sizeof(unsigned long long), d.stream));
+    HIP_TRY(d.counters.reserve(8));
+    HIP_TRY(hipMemsetAsync(d.counters.p, 0, 8 * sizeof(unsigned long long), d.stream));
     if (ctx->profile_sections) {
         HIP_TRY(d.prof.reserve(3 * ptk::SEC_COUNT));
         HIP_TRY(hipMemsetAsync(d.prof.p, 0, 3 * ptk::SEC_COUNT * sizeof(unsigned long long), d.stream));
@@ -339,6 +446,9 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, cons
     }
     const size_t njobs_max = (size_t)ns * fr.chunk;
     HIP_TRY(d.L.reserve(3 * njobs_max));
+    HIP_TRY(d.ray.reserve(6 * njobs_max));
+    HIP_TRY(d.ray_rng.reserve(njobs_max));
+    HIP_TRY(d.ray_ndraw.reserve(njobs_max));
     if (fr.stats_on) {
         HIP_TRY(d.job_seg.reserve(njobs_max));
         HIP_TRY(d.job_draw.reserve(njobs_max));
@@ -351,12 +461,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, cons
     const size_t lds = (size_t)fr.nobj * sizeof(DevObj) + (size_t)fr.nmat * sizeof(DevMat);
     if (lds > 160 * 1024) return fail(PT_ERR_INVALID, "scene does not fit the 160 KiB LDS of a CU");
     int nb = 0;
-    if (ctx->profile_sections)
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<false, true>, PT_BLOCK, lds));
-    else if (fr.stats_on)
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<true, false>, PT_BLOCK, lds));
-    else
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::trace_kernel<false, false>, PT_BLOCK, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan), PT_BLOCK, lds));
     d.blocks_per_cu = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
     return PT_OK;
 }
@@ -377,7 +482,13 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     TraceBuffers B;
     B.objs = d.objs.p;
     B.mats = d.mats.p;
+    B.bsph = d.bsph.p;
+    B.bbox = d.bbox.p;
+    B.plane_idx = d.plane_idx.p;
     B.L = d.L.p;
+    B.ray = d.ray.p;
+    B.ray_rng = d.ray_rng.p;
+    B.ray_ndraw = d.ray_ndraw.p;
     B.job_seg = fr.stats_on ? d.job_seg.p : nullptr;
     B.job_draw = fr.stats_on ? d.job_draw.p : nullptr;
     B.queue = d.queue.p;
@@ -405,12 +516,10 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
         grid = std::max(1u, std::min(grid, (waves_needed + 3u) / 4u));
         EventPair &e = d.ev_trace[d.n_trace++];
         HIP_TRY(hipEventRecord(e.a, d.stream));
-        if (ctx->profile_sections)
-            hipLaunchKernelGGL((ptk::trace_kernel<false, true>), dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
-        else if (fr.stats_on)
-            hipLaunchKernelGGL((ptk::trace_kernel<true, false>), dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
-        else
-            hipLaunchKernelGGL((ptk::trace_kernel<false, false>), dim3(grid), dim3(PT_BLOCK), lds, d.stream, F, fr.cam, fr.sky, B);
+        hipLaunchKernelGGL(ptk::raygen_kernel, dim3((F.njobs + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, d.stream, F, fr.cam,
+                           d.ray.p, d.ray_rng.p, d.ray_ndraw.p);
+        hipLaunchKernelGGL(pick_trace(fr.stats_on, ctx->profile_sections, fr.scan), dim3(grid), dim3(PT_BLOCK), lds, d.stream, F,
+                           fr.sky, B);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e.b, d.stream));
     }
@@ -482,8 +591,9 @@ int32_t dev_collect(Device &d, pt_stats *st, int slot) {
     HIP_TRY(hipSetDevice(d.ordinal));
     HIP_TRY(hipStreamSynchronize(d.stream));
     if (d.nlocal == 0) return PT_OK;
-    unsigned long long c[4] = {0, 0, 0, 0};
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(c, d.counters.p, sizeof c, hipMemcpyDeviceToHost));
+    g_mismatches += c[4];
     st->segments += c[0];
     st->exit_scans += c[1];
     st->draws += c[2];
@@ -538,10 +648,12 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, std
     F.inv_width = 1.0 / (double)(cfg->width - 1);
     F.inv_height = 1.0 / (double)(cfg->height - 1);
     F.height_m1 = (double)(cfg->height - 1);
+    build_broad(world, fr);
+    fr.scan = (F.broad_ok && ctx->scan_mode != ptk::SCAN_UNIFORM) ? ctx->scan_mode : ptk::SCAN_UNIFORM;
     // chunk of samples per pass: bounded by the L budget and by 2^31 jobs
     uint32_t chunk = cfg->spp_chunk > 0 ? (uint32_t)cfg->spp_chunk : 0;
     const uint32_t slots = std::max(1u, max_slots);
-    if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * 24));
+    if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * 82));  // 24 B radiance + 58 B primary ray per job
     chunk = std::min<uint32_t>(chunk, (uint32_t)std::max(1, cfg->samples_per_px));
     chunk = std::min<uint32_t>(chunk, std::max(1u, 0x7fffffffu / slots));
     fr.chunk = chunk;
@@ -591,6 +703,11 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
         long c = std::atol(e);
         if (c >= 64 && c % 64 == 0) ctx->claim = (uint32_t)c;
     }
+    if (const char *e = std::getenv("PTCORE_SCAN")) {
+        if (!std::strcmp(e, "uniform")) ctx->scan_mode = ptk::SCAN_UNIFORM;
+        else if (!std::strcmp(e, "verify")) ctx->scan_mode = ptk::SCAN_VERIFY;
+        else ctx->scan_mode = ptk::SCAN_BROAD;
+    }
     if (const char *e = std::getenv("PTCORE_PROFILE")) ctx->profile_sections = std::atoi(e) != 0;
     if (const char *e = std::getenv("PTCORE_BLOCKS_PER_CU")) {
         long c = std::atol(e);
@@ -624,7 +741,8 @@ void pt_destroy(pt_ctx *ctx) {
     for (Device &d : ctx->devs) {
         if (hipSetDevice(d.ordinal) != hipSuccess) continue;
         if (d.own_stream) (void)hipStreamSynchronize(d.own_stream);
-        d.objs.release(); d.mats.release(); d.L.release(); d.job_seg.release(); d.job_draw.release();
+        d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release();
+        d.objs.release(); d.mats.release(); d.bsph.release(); d.bbox.release(); d.plane_idx.release(); d.L.release(); d.job_seg.release(); d.job_draw.release();
         d.prof.release();
         d.acc.release(); d.acc_seg.release(); d.acc_draw.release(); d.tiles_rgba.release();
         d.tiles_accum.release(); d.tiles_seg.release(); d.tiles_draw.release(); d.queue.release();
@@ -648,6 +766,11 @@ int32_t pt_debug_profile(pt_ctx *ctx, uint64_t *out, int32_t n) {
     if (!ctx->profile_sections) return fail(PT_ERR_STATE, "set PTCORE_PROFILE=1 before pt_create");
     for (int32_t i = 0; i < n && i < 3 * ptk::SEC_COUNT; i++) out[i] = g_profile_scratch[i];
     return 3 * ptk::SEC_COUNT;
+}
+
+int64_t pt_debug_scan_mismatches(pt_ctx *ctx) {
+    (void)ctx;
+    return (int64_t)g_mismatches;
 }
 
 int32_t pt_shard_tiles(int32_t width, int32_t height, const pt_shard *shard, int32_t *ntiles_local, int32_t *ntiles_x,

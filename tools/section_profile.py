@@ -9,7 +9,7 @@ from path_trace_golang_amd import capi, hip, scene
 name = sys.argv[1] if len(sys.argv) > 1 else "gpu_showcase"
 w, h, spp, d = (int(x) for x in (sys.argv[2:6] if len(sys.argv) >= 6 else (1920, 1080, 42, 8)))
 SEC = ["iter", "raygen", "lens", "scan", "sph_root", "sph_root2", "hitrec", "cosine", "diel", "exitpost", "rr",
-       "finish", "sky", "unitdir"]
+       "finish", "sky", "unitdir", "broad", "nar_sph", "nar_box", "plane"]
 ctx = capi.Context(ndev=1)
 sc = scene.load("scenes/%s.json" % name)
 img = np.zeros((h, w, 4), np.uint8)
