@@ -18,10 +18,11 @@ summed over all ranks and steps / wall time (max over ranks).  Primary samples/s
 reported beside it.  The 5 KB scene upload is inside the timed region; the output
 stays in HBM.
 
-roofline: the dominant kernel is ptk::trace_kernel.  It is FP64-VALU bound, not HBM
+roofline: the dominant kernel is ptk::trace_kernel.  It is VALU-issue bound, not HBM
 bound (its path state lives in registers): "roofline" states its algorithmic HBM
-bytes honestly against the 8 TB/s peak (a tiny fraction by design) and
-"roofline_fp64" states the binding resource.  See DESIGN.md.
+bytes (58 B primary ray in + 24 B radiance out per sample) honestly against the
+8 TB/s peak (a small fraction by design) and "roofline_fp64" states the binding
+resource.  See DESIGN.md.
 """
 from __future__ import annotations
 
@@ -44,6 +45,19 @@ def seg_flops(n_sphere: int, n_box: int, n_plane: int) -> float:
     return 23.0 * n_sphere + 12.0 * n_box + 14.0 * n_plane + 150.0
 
 
+def host_cpu_quota() -> int:
+    """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 128))
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,7 +71,7 @@ def main() -> int:
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--spp-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=2, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
     import torch  # first: libptcore must resolve libamdhip64.so.7 to the copy torch already loaded
@@ -153,12 +167,12 @@ def main() -> int:
         n_launch = sum(s.trace_launches for s in stats)
         resolve_ms = sum(s.resolve_ms for s in stats)
         avg_launch_s = (trace_ms / max(1, n_launch)) * 1e-3
-        # algorithmic HBM bytes of one trace launch: 24 B of radiance per job + the world once per block
+        # algorithmic HBM bytes of one trace launch, per sample: the primary ray written by raygen_kernel
+        # (6 doubles + 8 B stream state + 2 B draw count = 58 B) in, 24 B of radiance out
         chunk = stats[0].spp_chunk if stats else 0
-        ntl_local = ntl.value
         spp_per_launch = args.spp / max(1, (n_launch / steps))
-        jobs_per_launch = ntl_local * 1024.0 * spp_per_launch
-        alg_bytes = 24.0 * jobs_per_launch
+        jobs_per_launch = (sum(s.samples for s in stats) / steps) / max(1e-9, args.spp) * spp_per_launch
+        alg_bytes = (58.0 + 24.0) * jobs_per_launch
         achieved_gbs = alg_bytes / max(avg_launch_s, 1e-12) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -196,12 +210,12 @@ def main() -> int:
             "segments_per_sample": segments / max(samples, 1.0),
             "exit_scans_per_segment": exits / max(segments, 1.0),
             "pixel_rmse_vs_cpu_ref": None,
-            "roofline": {"bound": "hbm", "kernel": "ptk::trace_kernel<false>", "achieved": achieved_gbs,
+            "roofline": {"bound": "hbm", "kernel": "ptk::trace_kernel<false,false,1>", "achieved": achieved_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "alg_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": n_launch / steps,
-                         "note": "register-resident paths: HBM carries only 24 B of radiance per sample; "
-                                 "the binding resource is FP64 VALU, see roofline_fp64"},
+                         "note": "register-resident paths: HBM carries 82 B per SAMPLE (primary ray in, radiance "
+                                 "out), nothing per bounce; the binding resource is VALU issue, see roofline_fp64"},
             "roofline_fp64": {"bound": "fp64_valu", "achieved": fp64_tops, "peak": FP64_PEAK_NOFMA_TOPS,
                               "unit": "Tflop/s (unfused)", "frac": fp64_tops / FP64_PEAK_NOFMA_TOPS,
                               "alg_flops_per_segment": fseg,
@@ -211,26 +225,30 @@ def main() -> int:
         if not args.no_cpu_baseline and world == 1:
             from oracle import ora  # CPU restatement of the reference engine: the timed baseline only
 
+            import numpy as np
+
+            workers = host_cpu_quota()
             osc = ora.Scene.load(os.path.join(ROOT, "scenes", args.scene + ".json"))
-            r = ora.render(osc, W, H, args.cpu_spp, args.depth, seed=args.seed, want=("rgba", "accum"))
+            # bounded sample of the same workload: full frame, 1 spp to size it, then ~cpu_seconds of CPU work
+            r1 = ora.render(osc, W, H, 1, args.depth, seed=args.seed, workers=workers, want=("accum",))
+            cpu_spp = int(max(1, min(64, round(args.cpu_seconds / max(r1["stats"]["seconds"], 1e-3)))))
+            r = ora.render(osc, W, H, cpu_spp, args.depth, seed=args.seed, workers=workers, want=("rgba", "accum"))
             cst = r["stats"]
             out["cpu_baseline"] = {
                 "value": cst["segments"] / cst["seconds"] / 1e6, "unit": "Msamples/s", "cores": cst["workers"],
                 "kind": "port",
-                "sample": "same scene and frame size, %d of %d spp (%.1f s of CPU work on %d threads); C restatement "
-                          "of internal/engine (oracle/pt_oracle.c), the Go reference cannot be built here"
-                          % (args.cpu_spp, args.spp, cst["seconds"], cst["workers"]),
+                "sample": "same scene and frame size, %d of %d spp (%.1f s of CPU work on %d threads = the box's CPU quota); "
+                          "C restatement of internal/engine (oracle/pt_oracle.c): the Go reference cannot be built here"
+                          % (cpu_spp, args.spp, cst["seconds"], cst["workers"]),
                 "primary_msamples_per_s": cst["samples"] / cst["seconds"] / 1e6,
             }
             out["gpu_over_cpu"] = out["value"] / max(out["cpu_baseline"]["value"], 1e-12)
-            # parity spot check on the same sample: GPU at cpu_spp vs the oracle image
-            import numpy as np
-
+            # parity on the same sample: GPU at cpu_spp vs the CPU image
             img = np.zeros((H, W, 4), np.uint8)
             acc = np.zeros((H, W, 3), np.float64)
-            hip.render(sc, hip.RenderConfig(W, H, args.cpu_spp, args.depth, args.seed), img, None, acc, ctx=ctx)
-            g = np.sqrt(np.clip(acc / args.cpu_spp, 0, 1))
-            o = np.sqrt(np.clip(r["accum"] / args.cpu_spp, 0, 1))
+            hip.render(sc, hip.RenderConfig(W, H, cpu_spp, args.depth, args.seed), img, None, acc, ctx=ctx)
+            g = np.sqrt(np.clip(acc / cpu_spp, 0, 1))
+            o = np.sqrt(np.clip(r["accum"] / cpu_spp, 0, 1))
             out["pixel_rmse_vs_cpu_ref"] = float(np.sqrt(np.mean((g - o) ** 2)))
             out["rgba8_bytes_differing"] = int(np.count_nonzero(img != r["rgba"]))
         print(json.dumps(out), flush=True)
