@@ -96,6 +96,7 @@ SYMBOLS = [
                                       _vp]),
     ("pt_debug_profile", C.c_int32, [_vp, C.POINTER(C.c_uint64), C.c_int32]),
     ("pt_debug_scan_mismatches", C.c_int64, [_vp]),
+    ("pt_debug_bvh_check", C.c_int32, [C.POINTER(PtScene), C.POINTER(C.c_int32)]),
 ]
 
 

@@ -65,6 +65,26 @@ struct alignas(16) BroadBox {
 };
 static_assert(sizeof(BroadBox) == 32, "BroadBox layout");
 
+// BVH node for scenes beyond the 64-object bitmask: both children's FP32 boxes (inflated, rounded
+// outward) in one 64-byte record.  Child codes: >= 0 internal node index; < 0 leaf, with
+// ~code = first | (count-1) << 28 into the leaf-ordered object array.
+struct alignas(64) BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t c0, c1;
+    int32_t flags, pad;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode layout");
+
+// Object as stored in leaf order for the BVH path: the 80-byte DevObj plus its index in file order
+// (tie rules and the winner look-up use the original index).
+struct alignas(16) BvhObj {
+    DevObj o;
+    int32_t index;
+    int32_t pad[3];
+};
+static_assert(sizeof(BvhObj) == 96, "BvhObj layout");
+
 struct DevCamera {     // camera.go:9-17 after newCamera (camera.go:19-58)
     double origin[3];
     double lower_left[3];
@@ -95,6 +115,9 @@ struct DevFrame {
     uint32_t njobs;      // nlocal*16*S*64
     uint32_t claim;      // jobs a wave claims per queue pop (multiple of 64)
     int32_t n_bsph, n_bbox, n_plane;  // broad-phase record counts; planes are always tested exactly
+    int32_t n_bvh_nodes, n_bvh_objs;  // BVH path (more than 64 objects)
+    int32_t world_in_lds;             // 1: DevObj/DevMat copies are staged in LDS (small scenes)
+    int32_t pad_i;
     int32_t broad_ok;    // 1: nobj <= 64 and every finite object has finite bounds -> broad/narrow scan usable
     uint64_t all_mask;   // bit i set for every object i
     uint64_t diel_mask;  // objects whose material is dielectric
@@ -113,6 +136,8 @@ struct TraceBuffers {
     const BroadSphere *bsph;
     const BroadBox *bbox;
     const int32_t *plane_idx;
+    const BvhNode *bvh_nodes;
+    const BvhObj *bvh_objs;
     const double *ray;    // [6][njobs] primary rays of the chunk (raygen_kernel)
     const unsigned long long *ray_rng;  // [njobs] stream state after the camera draws
     const uint16_t *ray_ndraw;          // [njobs] draws used by ray generation; 0xffff = pixel outside the frame

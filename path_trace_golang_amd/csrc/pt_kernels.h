@@ -16,7 +16,11 @@
 //                                   builds a per-lane candidate bitmask, then each lane runs
 //                                   the exact FP64 tests only on its own candidates (per-lane
 //                                   look-ups in the LDS copy of the world).  Needs <= 64 objects.
-//                     SCAN_VERIFY   runs both and counts disagreements (diagnostics).
+//                     SCAN_BVH      more than 64 objects: per-lane traversal of a binary BVH whose
+//                                   FP32 node boxes are conservative (same inflation as the broad
+//                                   phase), exact FP64 tests at the leaves; nodes and objects are
+//                                   read from HBM/L2, the traversal stack lives in LDS.
+//                     SCAN_VERIFY*  run a culled strategy AND the plain scan, count disagreements.
 //   resolve_kernel  per pixel slot, adds the chunk's sample radiances IN SAMPLE ORDER
 //                   to the running sum (renderer.go:186), and on request finishes the
 //                   pixel: 1/spp, sqrt gamma, *255.999, clamp, truncate (renderer.go:190-221).
@@ -92,7 +96,8 @@ enum { SEC_ITER = 0, SEC_RAYGEN, SEC_LENS, SEC_SCAN, SEC_SPH_ROOT, SEC_SPH_ROOT2
        SEC_DIEL, SEC_EXITPOST, SEC_RR, SEC_FINISH, SEC_SKY, SEC_UNITDIR, SEC_BROAD, SEC_NSPH, SEC_NBOX, SEC_PLANE, SEC_COUNT };
 
 
-enum { SCAN_UNIFORM = 0, SCAN_BROAD = 1, SCAN_VERIFY = 2 };
+enum { SCAN_UNIFORM = 0, SCAN_BROAD = 1, SCAN_VERIFY = 2, SCAN_BVH = 3, SCAN_VERIFY_BVH = 4 };
+#define PT_BVH_STACK 48
 
 // Diagnostic hooks handed to the scan routines (all no-ops unless PROF).
 struct ProfHooks {
@@ -225,7 +230,7 @@ __device__ __forceinline__ bool wins(int mode, bool is_box, int i, double t, int
     if (!(t == tmax)) return false;
     if (best < 0) return !is_box;  // tmax is still MaxFloat64: inclusive tests accept t == MaxFloat64, the box does not
     if (mode != 0) return i < best;
-    if (is_box) return false;
+    if (is_box) return best_is_box && i < best;  // boxes: the earlier one keeps an exact tie, and never beats a sphere/plane
     return best_is_box || i > best;
 }
 
@@ -349,6 +354,131 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     }
 }
 
+// Closest hit / exit search through the BVH.  Traversal order and culling only decide which
+// objects get the exact test; `wins` makes the result independent of that order.
+template <bool PROF, typename ObjPtr, typename IdxPtr>
+__device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr g_pl, const BvhNode *__restrict__ nodes,
+                                         const BvhObj *__restrict__ bobjs, int *stack /* this lane's column, stride PT_BLOCK */,
+                                         const RayD &r, int mode, int &best, double &tmax, const ProfHooks &ph) {
+    const double tmin = mode ? 0.0001 : 0.001;
+    tmax = ptm::max_float64();
+    best = -1;
+    bool best_is_box = false;
+    const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+
+    PH_BEGIN(SEC_PLANE)
+    for (int k = 0; k < F.n_plane; k++) {
+        const int i = g_pl[k];
+        const auto &o = g_obj[i];
+        if (mode != 0 && !(o.kind & 0x100)) continue;
+        double t = 0;
+        if (plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t)) {
+            if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
+                          : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_PLANE, r, t))) {
+                best = i;
+                tmax = t;
+                best_is_box = false;
+            }
+        }
+    }
+    PH_END(SEC_PLANE)
+    if (F.n_bvh_objs == 0) return;
+
+    const float fox = (float)r.ox, foy = (float)r.oy, foz = (float)r.oz;
+    const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
+    const float fa = __builtin_fmaf(fdx, fdx, __builtin_fmaf(fdy, fdy, fdz * fdz));
+    const bool trust = (fa > 1e-30f) && (fa < 1e30f) && (__builtin_fabsf(fox) <= F.origin_bound) &&
+                       (__builtin_fabsf(foy) <= F.origin_bound) && (__builtin_fabsf(foz) <= F.origin_bound);
+    const float tminf = mode ? 9.9e-5f : 9.9e-4f;
+    const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
+    const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
+    float tmaxf = (float)tmax * 1.0000005f;  // >= tmax (MaxFloat64 becomes +inf)
+
+    int sp = 0;
+    int cur = 0;  // root
+    const int DONE = 0x7fffffff;
+    PH_BEGIN(SEC_BROAD)
+    while (__ballot(cur != DONE) != 0) {
+        // ---- descend through internal nodes until this lane sits on a leaf (or is done)
+        while (cur >= 0 && cur != DONE) {
+            const BvhNode nd = nodes[cur];
+            float t0a, t0b;
+            bool h0, h1;
+            {
+                const float tax = (nd.lo0[0] - fox) * ivxf, tbx = (nd.hi0[0] - fox) * ivxf;
+                const float tay = (nd.lo0[1] - foy) * ivyf, tby = (nd.hi0[1] - foy) * ivyf;
+                const float taz = (nd.lo0[2] - foz) * ivzf, tbz = (nd.hi0[2] - foz) * ivzf;
+                t0a = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)),
+                                      __builtin_fmaxf(__builtin_fminf(taz, tbz), tminf));
+                const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
+                                                 __builtin_fminf(__builtin_fmaxf(taz, tbz), tmaxf));
+                h0 = !(t1 < t0a);
+            }
+            {
+                const float tax = (nd.lo1[0] - fox) * ivxf, tbx = (nd.hi1[0] - fox) * ivxf;
+                const float tay = (nd.lo1[1] - foy) * ivyf, tby = (nd.hi1[1] - foy) * ivyf;
+                const float taz = (nd.lo1[2] - foz) * ivzf, tbz = (nd.hi1[2] - foz) * ivzf;
+                t0b = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)),
+                                      __builtin_fmaxf(__builtin_fminf(taz, tbz), tminf));
+                const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
+                                                 __builtin_fminf(__builtin_fmaxf(taz, tbz), tmaxf));
+                h1 = !(t1 < t0b);
+            }
+            if (!trust) { h0 = true; h1 = true; t0a = 0; t0b = 0; }  // rays outside the analysed range visit everything
+            if (h0 && h1) {
+                const bool first0 = !(t0b < t0a);  // nearer child first
+                stack[sp * PT_BLOCK] = first0 ? nd.c1 : nd.c0;
+                sp++;
+                cur = first0 ? nd.c0 : nd.c1;
+            } else if (h0) {
+                cur = nd.c0;
+            } else if (h1) {
+                cur = nd.c1;
+            } else if (sp > 0) {
+                sp--;
+                cur = stack[sp * PT_BLOCK];
+            } else {
+                cur = DONE;
+            }
+        }
+        // ---- leaf: exact tests
+        if (cur != DONE) {
+            PH_BEGIN(SEC_NSPH)
+            const uint32_t code = ~(uint32_t)cur;
+            const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                const BvhObj &bo = bobjs[first + k];
+                const int kind = bo.o.kind & 0xff;
+                if (mode != 0 && !(bo.o.kind & 0x100)) continue;
+                const int i = bo.index;
+                double t = 0;
+                bool valid;
+                const bool is_box = kind == KIND_BOX;
+                if (is_box)
+                    valid = box_exact(bo.o.a[0], bo.o.a[1], bo.o.a[2], bo.o.b[0], bo.o.b[1], bo.o.b[2], r, ivx, ivy, ivz, tmin,
+                                      ptm::max_float64(), t);
+                else
+                    valid = sphere_exact(bo.o.a[0], bo.o.a[1], bo.o.a[2], bo.o.radius_sq, r, a, tmin, tmax, t);
+                if (valid && wins(mode, is_box, i, t, best, best_is_box, tmax) &&
+                    (mode == 0 || exit_candidate_ok(bo.o, kind, r, t))) {
+                    best = i;
+                    tmax = t;
+                    best_is_box = is_box;
+                    tmaxf = (float)tmax * 1.0000005f;
+                }
+            }
+            if (sp > 0) {
+                sp--;
+                cur = stack[sp * PT_BLOCK];
+            } else {
+                cur = DONE;
+            }
+            PH_END(SEC_NSPH)
+        }
+    }
+    PH_END(SEC_BROAD)
+}
+
 // Ray generation pre-pass: one thread per job of the chunk, all lanes busy and neighbouring
 // lanes on neighbouring pixels.  Per job: stream init, u then v (renderer.go:182-183),
 // camera.getRay with the lens rejection loop (camera.go:60-74, math.go:74-84).  Writes the primary
@@ -435,20 +565,25 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_kernel(const DevFrame F, cons
 template <bool STATS, bool PROF, int SCAN>
 __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const DevSky sky, const TraceBuffers B) {
     extern __shared__ __align__(16) unsigned char smem[];
-    DevObj *s_obj = reinterpret_cast<DevObj *>(smem);
-    DevMat *s_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
-    {
-        // stage the world in LDS: the winner look-up after the scan is per lane
+    constexpr bool BIG = (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH);
+    // small scenes: the world is staged in LDS (the winner look-up after the scan is per lane);
+    // BVH scenes: LDS holds the traversal stacks and the world is read from HBM/L2
+    DevObj *lds_obj = reinterpret_cast<DevObj *>(smem);
+    DevMat *lds_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
+    int *lds_stack = reinterpret_cast<int *>(smem);
+    if (!BIG) {
         const uint64_t *g0 = reinterpret_cast<const uint64_t *>(B.objs);
-        uint64_t *l0 = reinterpret_cast<uint64_t *>(s_obj);
+        uint64_t *l0 = reinterpret_cast<uint64_t *>(lds_obj);
         const int n0 = F.nobj * (int)(sizeof(DevObj) / 8);
         for (int i = threadIdx.x; i < n0; i += PT_BLOCK) l0[i] = g0[i];
         const uint64_t *g1 = reinterpret_cast<const uint64_t *>(B.mats);
-        uint64_t *l1 = reinterpret_cast<uint64_t *>(s_mat);
+        uint64_t *l1 = reinterpret_cast<uint64_t *>(lds_mat);
         const int n1 = F.nmat * (int)(sizeof(DevMat) / 8);
         for (int i = threadIdx.x; i < n1; i += PT_BLOCK) l1[i] = g1[i];
+        __syncthreads();
     }
-    __syncthreads();
+    const DevObj *const s_obj = BIG ? B.objs : lds_obj;
+    const DevMat *const s_mat = BIG ? B.mats : lds_mat;
 
     // The world is immutable for the whole launch: read it through the constant address
     // space so the wave-uniform scan index turns into scalar (SGPR) loads.
@@ -575,6 +710,33 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                                   (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100);
                 if (__ballot(!tame) != 0) scan_uniform(F, g_obj, ray, mode, best, tmax);
                 else scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, ray, mode, best, tmax, ph);
+            } else if (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) {
+                const double a_ = dx * dx + dy * dy + dz * dz;
+                const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
+                                  (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100);
+                if (__ballot(!tame) != 0) {
+                    scan_uniform(F, g_obj, ray, mode, best, tmax);
+                } else {
+                    scan_bvh<PROF>(F, g_obj, g_pl, B.bvh_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, mode, best, tmax, ph);
+                    if (SCAN == SCAN_VERIFY_BVH) {
+                        int best2;
+                        double tmax2;
+                        scan_uniform(F, g_obj, ray, mode, best2, tmax2);
+                        if (best != best2 || (best >= 0 && !(tmax == tmax2))) {
+                            c_mismatch++;
+                            // diagnostics: one disagreeing segment (racy, any one will do)
+                            unsigned long long *dbg = B.counters + 8;
+                            dbg[0] = ((unsigned long long)(uint32_t)best << 32) | (uint32_t)best2;
+                            dbg[1] = ptm::to_bits(tmax);
+                            dbg[2] = ptm::to_bits(tmax2);
+                            dbg[3] = (unsigned long long)mode;
+                            dbg[4] = ptm::to_bits(ox); dbg[5] = ptm::to_bits(oy); dbg[6] = ptm::to_bits(oz);
+                            dbg[7] = ptm::to_bits(dx); dbg[8] = ptm::to_bits(dy); dbg[9] = ptm::to_bits(dz);
+                        }
+                        best = best2;
+                        tmax = tmax2;
+                    }
+                }
             } else {
                 int best2;
                 double tmax2;
@@ -841,7 +1003,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         atomicAdd(&B.counters[2], (unsigned long long)w_draw);
         atomicAdd(&B.counters[3], (unsigned long long)w_samples);
     }
-    if (SCAN == SCAN_VERIFY) {
+    if (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_BVH) {
         const uint32_t w_mis = wave_sum(c_mismatch);
         if (lane == 0 && w_mis) atomicAdd(&B.counters[4], (unsigned long long)w_mis);
     }

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/ptcore.h"
+#include "pt_bvh.h"
 #include "pt_device.h"
 #include "pt_kernels.h"
 #include "pt_math.h"
@@ -32,7 +33,8 @@ namespace {
 
 thread_local std::string g_last_error;
 unsigned long long g_profile_scratch[3 * ptk::SEC_COUNT] = {};
-unsigned long long g_mismatches = 0;  // SCAN_VERIFY disagreements of the last collected frame
+unsigned long long g_mismatches = 0;
+unsigned long long g_mismatch_sample[10] = {};  // SCAN_VERIFY disagreements of the last collected frame
 
 int32_t fail(int32_t code, const std::string &msg) {
     g_last_error = msg;
@@ -81,6 +83,8 @@ struct Device {
     DevBuf<BroadSphere> bsph;
     DevBuf<BroadBox> bbox;
     DevBuf<int32_t> plane_idx;
+    DevBuf<BvhNode> bvh_nodes;
+    DevBuf<BvhObj> bvh_objs;
     DevBuf<double> L;
     DevBuf<double> ray;
     DevBuf<unsigned long long> ray_rng;
@@ -120,6 +124,10 @@ struct Frame {
     std::vector<BroadSphere> bsph;
     std::vector<BroadBox> bbox;
     std::vector<int32_t> plane_idx;
+    std::vector<BvhNode> bvh_nodes;
+    std::vector<BvhObj> bvh_objs;
+    int bvh_depth = 0;
+    size_t lds_bytes = 0;
     int scan = 0;  // ptk::SCAN_* used for this frame
     std::chrono::steady_clock::time_point t0;
 };
@@ -139,7 +147,7 @@ struct pt_ctx {
     size_t l_budget_bytes = (size_t)6 << 30;  // per-chunk job buffers (radiance + primary rays)
     uint32_t claim = 256;
     int max_blocks_per_cu = 8;
-    int scan_mode = ptk::SCAN_BROAD;  // PTCORE_SCAN=uniform|broad|verify
+    int scan_mode = -1;  // -1 = choose by scene size; PTCORE_SCAN=uniform|broad|verify|bvh|verify_bvh forces one
     unsigned long long last_mismatches = 0;
     bool profile_sections = false;  // PTCORE_PROFILE=1: diagnostic kernel build with per-section counters
     unsigned long long last_profile[3 * ptk::SEC_COUNT] = {};
@@ -384,13 +392,19 @@ using TraceFn = void (*)(const DevFrame, const DevSky, const TraceBuffers);
 
 // The shipping instantiations are <false,false,*>; STATS adds per-pixel counters, PROF the section profile.
 TraceFn pick_trace(bool stats, bool prof, int scan) {
-    if (prof) return scan == ptk::SCAN_UNIFORM ? ptk::trace_kernel<false, true, ptk::SCAN_UNIFORM>
-                                                : ptk::trace_kernel<false, true, ptk::SCAN_BROAD>;
-    if (scan == ptk::SCAN_VERIFY) return stats ? ptk::trace_kernel<true, false, ptk::SCAN_VERIFY>
-                                                : ptk::trace_kernel<false, false, ptk::SCAN_VERIFY>;
-    if (scan == ptk::SCAN_BROAD) return stats ? ptk::trace_kernel<true, false, ptk::SCAN_BROAD>
-                                               : ptk::trace_kernel<false, false, ptk::SCAN_BROAD>;
-    return stats ? ptk::trace_kernel<true, false, ptk::SCAN_UNIFORM> : ptk::trace_kernel<false, false, ptk::SCAN_UNIFORM>;
+    using namespace ptk;
+    if (prof) {
+        if (scan == SCAN_UNIFORM) return trace_kernel<false, true, SCAN_UNIFORM>;
+        if (scan == SCAN_BVH || scan == SCAN_VERIFY_BVH) return trace_kernel<false, true, SCAN_BVH>;
+        return trace_kernel<false, true, SCAN_BROAD>;
+    }
+    switch (scan) {
+        case SCAN_BROAD: return stats ? trace_kernel<true, false, SCAN_BROAD> : trace_kernel<false, false, SCAN_BROAD>;
+        case SCAN_VERIFY: return stats ? trace_kernel<true, false, SCAN_VERIFY> : trace_kernel<false, false, SCAN_VERIFY>;
+        case SCAN_BVH: return stats ? trace_kernel<true, false, SCAN_BVH> : trace_kernel<false, false, SCAN_BVH>;
+        case SCAN_VERIFY_BVH: return stats ? trace_kernel<true, false, SCAN_VERIFY_BVH> : trace_kernel<false, false, SCAN_VERIFY_BVH>;
+        default: return stats ? trace_kernel<true, false, SCAN_UNIFORM> : trace_kernel<false, false, SCAN_UNIFORM>;
+    }
 }
 
 int32_t dev_events(Device &d, std::vector<EventPair> &v, size_t need) {
@@ -429,11 +443,17 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, cons
         HIP_TRY(hipMemcpyAsync(d.bbox.p, fr.bbox.data(), fr.bbox.size() * sizeof(BroadBox), hipMemcpyHostToDevice, d.stream));
     if (!fr.plane_idx.empty())
         HIP_TRY(hipMemcpyAsync(d.plane_idx.p, fr.plane_idx.data(), fr.plane_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+    HIP_TRY(d.bvh_nodes.reserve(std::max<size_t>(1, fr.bvh_nodes.size())));
+    HIP_TRY(d.bvh_objs.reserve(std::max<size_t>(1, fr.bvh_objs.size())));
+    if (!fr.bvh_nodes.empty())
+        HIP_TRY(hipMemcpyAsync(d.bvh_nodes.p, fr.bvh_nodes.data(), fr.bvh_nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, d.stream));
+    if (!fr.bvh_objs.empty())
+        HIP_TRY(hipMemcpyAsync(d.bvh_objs.p, fr.bvh_objs.data(), fr.bvh_objs.size() * sizeof(BvhObj), hipMemcpyHostToDevice, d.stream));
     // the copies above read pageable host vectors that die with the caller's scope
     HIP_TRY(hipStreamSynchronize(d.stream));
     HIP_TRY(d.queue.reserve(1));
-    HIP_TRY(d.counters.reserve(8));
-    HIP_TRY(hipMemsetAsync(d.counters.p, 0, 8 * sizeof(unsigned long long), d.stream));
+    HIP_TRY(d.counters.reserve(24));
+    HIP_TRY(hipMemsetAsync(d.counters.p, 0, 24 * sizeof(unsigned long long), d.stream));
     if (ctx->profile_sections) {
         HIP_TRY(d.prof.reserve(3 * ptk::SEC_COUNT));
         HIP_TRY(hipMemsetAsync(d.prof.p, 0, 3 * ptk::SEC_COUNT * sizeof(unsigned long long), d.stream));
@@ -458,8 +478,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, cons
         HIP_TRY(hipEventCreate(&d.ev_last));
     }
     // occupancy of the trace kernel for this scene's LDS footprint
-    const size_t lds = (size_t)fr.nobj * sizeof(DevObj) + (size_t)fr.nmat * sizeof(DevMat);
-    if (lds > 160 * 1024) return fail(PT_ERR_INVALID, "scene does not fit the 160 KiB LDS of a CU");
+    const size_t lds = fr.lds_bytes;
     int nb = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan), PT_BLOCK, lds));
     d.blocks_per_cu = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
@@ -485,6 +504,8 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     B.bsph = d.bsph.p;
     B.bbox = d.bbox.p;
     B.plane_idx = d.plane_idx.p;
+    B.bvh_nodes = d.bvh_nodes.p;
+    B.bvh_objs = d.bvh_objs.p;
     B.L = d.L.p;
     B.ray = d.ray.p;
     B.ray_rng = d.ray_rng.p;
@@ -510,7 +531,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
         }
     } else {
         HIP_TRY(hipMemsetAsync(d.queue.p, 0, sizeof(unsigned int), d.stream));
-        const size_t lds = (size_t)fr.nobj * sizeof(DevObj) + (size_t)fr.nmat * sizeof(DevMat);
+        const size_t lds = fr.lds_bytes;
         const uint32_t waves_needed = (F.njobs + 63u) / 64u;
         uint32_t grid = (uint32_t)(d.num_cu * d.blocks_per_cu);
         grid = std::max(1u, std::min(grid, (waves_needed + 3u) / 4u));
@@ -591,9 +612,10 @@ int32_t dev_collect(Device &d, pt_stats *st, int slot) {
     HIP_TRY(hipSetDevice(d.ordinal));
     HIP_TRY(hipStreamSynchronize(d.stream));
     if (d.nlocal == 0) return PT_OK;
-    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c[24] = {};
     HIP_TRY(hipMemcpy(c, d.counters.p, sizeof c, hipMemcpyDeviceToHost));
     g_mismatches += c[4];
+    if (c[4]) std::memcpy(g_mismatch_sample, c + 8, sizeof g_mismatch_sample);
     st->segments += c[0];
     st->exit_scans += c[1];
     st->draws += c[2];
@@ -649,7 +671,44 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, std
     F.inv_height = 1.0 / (double)(cfg->height - 1);
     F.height_m1 = (double)(cfg->height - 1);
     build_broad(world, fr);
-    fr.scan = (F.broad_ok && ctx->scan_mode != ptk::SCAN_UNIFORM) ? ctx->scan_mode : ptk::SCAN_UNIFORM;
+    // closest-hit strategy: <= 64 objects -> candidate bitmask; more -> BVH.  PTCORE_SCAN overrides.
+    int scan = ctx->scan_mode;
+    if (scan < 0) scan = F.broad_ok ? ptk::SCAN_BROAD : ptk::SCAN_BVH;
+    if ((scan == ptk::SCAN_BROAD || scan == ptk::SCAN_VERIFY) && !F.broad_ok)
+        scan = scan == ptk::SCAN_VERIFY ? ptk::SCAN_VERIFY_BVH : ptk::SCAN_BVH;
+    fr.scan = scan;
+    const bool big = scan == ptk::SCAN_BVH || scan == ptk::SCAN_VERIFY_BVH;
+    fr.bvh_nodes.clear();
+    fr.bvh_objs.clear();
+    if (big) {
+        std::vector<int32_t> finite;
+        double Bnd = 1.0;
+        for (size_t i = 0; i < world.size(); i++) {
+            const int kind = world[i].kind & 0xff;
+            if (kind == KIND_PLANE) continue;
+            finite.push_back((int32_t)i);
+            const ptbvh::Aabb bb = ptbvh::object_bounds(world[i]);
+            for (int k = 0; k < 3; k++) Bnd = std::max(Bnd, std::max(std::fabs(bb.lo[k]), std::fabs(bb.hi[k])));
+        }
+        if (!(Bnd < 1e30)) Bnd = INFINITY;
+        ptbvh::Built built = ptbvh::build(world, finite, Bnd * (1.0 / 4096.0));
+        if (built.depth > PT_BVH_STACK) return fail(PT_ERR_INVALID, "BVH deeper than the traversal stack");
+        fr.bvh_depth = built.depth;
+        fr.bvh_nodes = std::move(built.nodes);
+        fr.bvh_objs.resize(built.order.size());
+        for (size_t k = 0; k < built.order.size(); k++) {
+            std::memset(&fr.bvh_objs[k], 0, sizeof(BvhObj));
+            fr.bvh_objs[k].o = world[(size_t)built.order[k]];
+            fr.bvh_objs[k].index = built.order[k];
+        }
+    }
+    F.n_bvh_nodes = (int32_t)fr.bvh_nodes.size();
+    F.n_bvh_objs = (int32_t)fr.bvh_objs.size();
+    F.world_in_lds = big ? 0 : 1;
+    fr.lds_bytes = big ? (size_t)PT_BVH_STACK * PT_BLOCK * sizeof(int)
+                       : (size_t)fr.nobj * sizeof(DevObj) + (size_t)fr.nmat * sizeof(DevMat);
+    if (fr.lds_bytes > 160 * 1024)
+        return fail(PT_ERR_INVALID, "scene does not fit the 160 KiB LDS of a CU with this scan strategy (use the BVH: unset PTCORE_SCAN)");
     // chunk of samples per pass: bounded by the L budget and by 2^31 jobs
     uint32_t chunk = cfg->spp_chunk > 0 ? (uint32_t)cfg->spp_chunk : 0;
     const uint32_t slots = std::max(1u, max_slots);
@@ -706,7 +765,9 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
     if (const char *e = std::getenv("PTCORE_SCAN")) {
         if (!std::strcmp(e, "uniform")) ctx->scan_mode = ptk::SCAN_UNIFORM;
         else if (!std::strcmp(e, "verify")) ctx->scan_mode = ptk::SCAN_VERIFY;
-        else ctx->scan_mode = ptk::SCAN_BROAD;
+        else if (!std::strcmp(e, "bvh")) ctx->scan_mode = ptk::SCAN_BVH;
+        else if (!std::strcmp(e, "verify_bvh")) ctx->scan_mode = ptk::SCAN_VERIFY_BVH;
+        else ctx->scan_mode = -1;
     }
     if (const char *e = std::getenv("PTCORE_PROFILE")) ctx->profile_sections = std::atoi(e) != 0;
     if (const char *e = std::getenv("PTCORE_BLOCKS_PER_CU")) {
@@ -742,7 +803,7 @@ void pt_destroy(pt_ctx *ctx) {
         if (hipSetDevice(d.ordinal) != hipSuccess) continue;
         if (d.own_stream) (void)hipStreamSynchronize(d.own_stream);
         d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release();
-        d.objs.release(); d.mats.release(); d.bsph.release(); d.bbox.release(); d.plane_idx.release(); d.L.release(); d.job_seg.release(); d.job_draw.release();
+        d.objs.release(); d.mats.release(); d.bsph.release(); d.bbox.release(); d.plane_idx.release(); d.bvh_nodes.release(); d.bvh_objs.release(); d.L.release(); d.job_seg.release(); d.job_draw.release();
         d.prof.release();
         d.acc.release(); d.acc_seg.release(); d.acc_draw.release(); d.tiles_rgba.release();
         d.tiles_accum.release(); d.tiles_seg.release(); d.tiles_draw.release(); d.queue.release();
@@ -768,8 +829,88 @@ int32_t pt_debug_profile(pt_ctx *ctx, uint64_t *out, int32_t n) {
     return 3 * ptk::SEC_COUNT;
 }
 
+// Host-only: builds the BVH of `scene` exactly as a render would and checks its invariants.
+// out = {nodes, objects, depth, largest leaf, objects missing or duplicated, objects outside their
+// leaf's box, child boxes not inside the parent's box, plane count}.
+int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]) {
+    if (!scene || !out) return fail(PT_ERR_INVALID, "null argument");
+    if (scene->num_materials < 0 || scene->num_objects < 0) return fail(PT_ERR_INVALID, "negative scene counts");
+    std::vector<DevObj> world;
+    std::vector<DevMat> mats;
+    scene_to_world(*scene, world, mats);
+    std::vector<int32_t> finite;
+    double Bnd = 1.0;
+    int planes = 0;
+    for (size_t i = 0; i < world.size(); i++) {
+        if ((world[i].kind & 0xff) == KIND_PLANE) { planes++; continue; }
+        finite.push_back((int32_t)i);
+        const ptbvh::Aabb bb = ptbvh::object_bounds(world[i]);
+        for (int k = 0; k < 3; k++) Bnd = std::max(Bnd, std::max(std::fabs(bb.lo[k]), std::fabs(bb.hi[k])));
+    }
+    const double margin = Bnd * (1.0 / 4096.0);
+    ptbvh::Built b = ptbvh::build(world, finite, margin);
+    std::vector<int> seen(world.size(), 0);
+    int largest = 0, outside = 0, nested = 0;
+    struct Item { int32_t code; float lo[3], hi[3]; };
+    std::vector<Item> st;
+    if (!b.nodes.empty()) {
+        Item r;
+        r.code = 0;
+        for (int k = 0; k < 3; k++) { r.lo[k] = -INFINITY; r.hi[k] = INFINITY; }
+        st.push_back(r);
+    }
+    while (!st.empty()) {
+        Item it = st.back();
+        st.pop_back();
+        if (it.code >= 0) {
+            const BvhNode &nd = b.nodes[(size_t)it.code];
+            Item c0, c1;
+            c0.code = nd.c0; c1.code = nd.c1;
+            for (int k = 0; k < 3; k++) {
+                c0.lo[k] = nd.lo0[k]; c0.hi[k] = nd.hi0[k]; c1.lo[k] = nd.lo1[k]; c1.hi[k] = nd.hi1[k];
+                if (nd.lo0[k] < it.lo[k] || nd.hi0[k] > it.hi[k] || nd.lo1[k] < it.lo[k] || nd.hi1[k] > it.hi[k]) nested++;
+            }
+            st.push_back(c0);
+            st.push_back(c1);
+        } else {
+            const uint32_t code = ~(uint32_t)it.code;
+            const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
+            largest = std::max(largest, (int)count);
+            for (uint32_t k = 0; k < count; k++) {
+                const int32_t oi = b.order[first + k];
+                seen[(size_t)oi]++;
+                const ptbvh::Aabb bb = ptbvh::object_bounds(world[(size_t)oi]);
+                for (int a = 0; a < 3; a++)
+                    if ((double)it.lo[a] > bb.lo[a] - margin * 0.999 || (double)it.hi[a] < bb.hi[a] + margin * 0.999) { outside++; break; }
+            }
+        }
+    }
+    int bad = 0;
+    for (int32_t i : finite) {
+        // a scene of one object lists its leaf twice on purpose
+        if (seen[(size_t)i] < 1 || (seen[(size_t)i] > 1 && finite.size() > 1)) bad++;
+    }
+    out[0] = (int32_t)b.nodes.size();
+    out[1] = (int32_t)b.order.size();
+    out[2] = b.depth;
+    out[3] = largest;
+    out[4] = bad;
+    out[5] = outside;
+    out[6] = nested;
+    out[7] = planes;
+    return PT_OK;
+}
+
 int64_t pt_debug_scan_mismatches(pt_ctx *ctx) {
     (void)ctx;
+    if (g_mismatches && std::getenv("PTCORE_VERBOSE")) {
+        const unsigned long long *s = g_mismatch_sample;
+        double v[8];
+        for (int i = 0; i < 2; i++) std::memcpy(&v[i], &s[1 + i], 8);
+        for (int i = 0; i < 6; i++) std::memcpy(&v[2 + i], &s[4 + i], 8);
+        std::fprintf(stderr, "scan mismatch sample: culled best %d t %.17g | plain best %d t %.17g | mode %llu | o %.17g %.17g %.17g d %.17g %.17g %.17g\n",
+                     (int)(s[0] >> 32), v[0], (int)(uint32_t)s[0], v[1], s[3], v[2], v[3], v[4], v[5], v[6], v[7]);
+    }
     return (int64_t)g_mismatches;
 }
 

@@ -82,3 +82,35 @@ def test_shard_tile_counts_agree_with_python_tiling():
             assert a.value == len(tiling.shard_tiles(w, h, k, n)) and (b.value, c.value) == tiling.tile_grid(w, h)
     bad = capi.PtShard(3, 2)
     assert lib.pt_shard_tiles(64, 64, C.byref(bad), None, None, None) == capi.PT_ERR_INVALID
+
+
+def test_bvh_builder_invariants_on_cpu():
+    # host-only: the hierarchy used beyond 64 objects keeps every finite object in exactly one leaf, inside
+    # its leaf box, with nested boxes, leaves of at most four and a depth within the traversal stack
+    import ctypes as C
+
+    from conftest import SCENE_NAMES, scene_path
+    from path_trace_golang_amd import capi, hip, scene, synth
+
+    lib = capi.load()
+    cases = [synth.make_scene(n, 3) for n in (1, 2, 5, 64, 65, 500, 5000)] + [scene.load(scene_path(s)) for s in SCENE_NAMES]
+    for sc in cases:
+        flat = hip.FlatScene(sc)
+        out = (C.c_int32 * 8)()
+        assert lib.pt_debug_bvh_check(C.byref(flat.c), out) == 0
+        nodes, objs, depth, leaf, bad, outside, nested, planes = list(out)
+        finite = sum(1 for o in sc.objects if o.type in ("sphere", "sphere_light", "box"))
+        assert objs == finite and planes == sum(1 for o in sc.objects if o.type == "plane")
+        assert bad == 0 and outside == 0 and nested == 0
+        assert leaf <= 4 and depth <= 48 and nodes >= 1
+
+
+def test_synthetic_scene_is_reproducible_and_in_schema(tmp_path):
+    from path_trace_golang_amd import scene, synth
+
+    a, b, c = synth.make_scene(200, 5), synth.make_scene(200, 5), synth.make_scene(200, 6)
+    assert a == b and a != c
+    assert sum(1 for o in a.objects if o.type != "plane") == 200
+    p = str(tmp_path / "synth.json")
+    scene.save(p, a)
+    assert scene.load(p) == a  # same JSON schema as the reference's scene files

@@ -2,7 +2,7 @@
 """Runs the PTCORE_SCAN=verify build on big workloads: both closest-hit strategies on every segment,
 prints how many segments disagreed (must be 0)."""
 import os, sys
-os.environ["PTCORE_SCAN"] = "verify"
+os.environ.setdefault("PTCORE_SCAN", "verify")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from path_trace_golang_amd import capi, hip, scene
