@@ -117,6 +117,8 @@ struct DevFrame {
     int32_t n_bsph, n_bbox, n_plane;  // broad-phase record counts; planes are always tested exactly
     int32_t n_bvh_nodes, n_bvh_objs;  // BVH path (more than 64 objects)
     int32_t world_in_lds;             // 1: DevObj/DevMat copies are staged in LDS (small scenes)
+    int32_t bvh_root;                 // root node of the hierarchy over every finite object, -1 if none
+    int32_t bvh_root_exit;            // root of the hierarchy over dielectric objects only, -1 if none
     int32_t pad_i;
     int32_t broad_ok;    // 1: nobj <= 64 and every finite object has finite bounds -> broad/narrow scan usable
     uint64_t all_mask;   // bit i set for every object i
@@ -124,6 +126,7 @@ struct DevFrame {
     uint64_t sphere_mask, box_mask;
     float origin_bound;  // rays whose origin leaves [-origin_bound, origin_bound]^3 keep every candidate
     float pad_f;
+    double scene_bound;  // Bs: every finite object (inflated) lies inside [-Bs, Bs]^3
     uint64_t seed_key;   // ptm::seed_key(seed)
     double inv_width;    // 1/(W-1)  renderer.go:95
     double inv_height;   // 1/(H-1)  renderer.go:96

@@ -105,6 +105,7 @@ struct ProfHooks {
     uint32_t *lanes;
     unsigned long long *cyc;
     uint32_t lane;
+    unsigned long long *dbg;  // counters + 8 (diagnostic sample slot)
 };
 #define PH_BEGIN(id)                                                              \
     unsigned long long pht_##id = 0;                                              \
@@ -265,13 +266,34 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     PH_END(SEC_PLANE)
     // ---- broad phase
     PH_BEGIN(SEC_BROAD)
-    const float fox = (float)r.ox, foy = (float)r.oy, foz = (float)r.oz;
+    // Rays that start far outside the scene (bounces off the infinite ground plane) are clipped in FP64
+    // against the cube [-Bs, Bs]^3 holding every finite object: a miss means no sphere or box can be hit,
+    // otherwise the FP32 tests run from the entry point (parameters relative to ts), inside the range the
+    // margin analysis covers.  v_min/v_max skip the NaN of a 0 * inf slab boundary: conservative.
+    double ts = 0;
+    bool outside_all = false;
+    {
+        const double Bs = F.scene_bound;
+        if (!(ptm::f_abs(r.ox) <= Bs && ptm::f_abs(r.oy) <= Bs && ptm::f_abs(r.oz) <= Bs)) {
+            const double ix = 1 / r.dx, iy = 1 / r.dy, iz = 1 / r.dz;
+            const double x0 = (-Bs - r.ox) * ix, x1 = (Bs - r.ox) * ix;
+            const double y0 = (-Bs - r.oy) * iy, y1 = (Bs - r.oy) * iy;
+            const double z0 = (-Bs - r.oz) * iz, z1 = (Bs - r.oz) * iz;
+            const double te = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmin(z0, z1));
+            const double tx = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmax(z0, z1));
+            outside_all = te > tx || tx < tmin || te > tmax;
+            ts = te > 0 ? te : 0;
+            if (outside_all) ts = 0;
+        }
+    }
+    const float fox = (float)(r.ox + r.dx * ts), foy = (float)(r.oy + r.dy * ts), foz = (float)(r.oz + r.dz * ts);
     const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
     const float fa = __builtin_fmaf(fdx, fdx, __builtin_fmaf(fdy, fdy, fdz * fdz));
     // written so that NaN lands on "keep everything"
     const bool trust = (fa > 1e-30f) && (fa < 1e30f) && (__builtin_fabsf(fox) <= F.origin_bound) &&
                        (__builtin_fabsf(foy) <= F.origin_bound) && (__builtin_fabsf(foz) <= F.origin_bound);
-    const float tminf = mode ? 9.9e-5f : 9.9e-4f;  // a little below tMin
+    float tminf = (float)(tmin - ts);  // FP32 parameters are relative to the entry point
+    tminf -= __builtin_fabsf(tminf) * 1e-2f + 1e-6f;  // a little below tMin - ts
     const float inv_a = __builtin_amdgcn_rcpf(fa);
     uint32_t clo = 0, chi = 0;
     for (int k = 0; k < F.n_bsph; k++) {
@@ -306,6 +328,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     }
     uint64_t cand = ((uint64_t)chi << 32) | clo;
     if (!trust) cand = F.sphere_mask | F.box_mask;
+    if (outside_all) cand = 0;
     if (mode != 0) cand &= F.diel_mask;
     PH_END(SEC_BROAD)
 
@@ -382,25 +405,46 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
         }
     }
     PH_END(SEC_PLANE)
-    if (F.n_bvh_objs == 0) return;
+    const int root = mode ? F.bvh_root_exit : F.bvh_root;
+    if (root < 0) return;
 
-    const float fox = (float)r.ox, foy = (float)r.oy, foz = (float)r.oz;
+    const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
+    // Rays that start far outside the scene (a bounce off the infinite ground plane hundreds of units
+    // away) would lose the FP32 margin analysis, which assumes |origin| <= 4B.  Clip them in FP64 against
+    // the cube [-Bs, Bs]^3 that holds every finite object: a ray that misses the cube cannot hit any of
+    // them, the others are re-based to their entry point (ts) for the FP32 node tests.  v_min/v_max skip
+    // NaNs (0 * inf on a slab boundary), which leaves that slab unconstrained: conservative.
+    double ts = 0;
+    const double Bs = F.scene_bound;
+    if (!(ptm::f_abs(r.ox) <= Bs && ptm::f_abs(r.oy) <= Bs && ptm::f_abs(r.oz) <= Bs)) {
+        const double x0 = (-Bs - r.ox) * ivx, x1 = (Bs - r.ox) * ivx;
+        const double y0 = (-Bs - r.oy) * ivy, y1 = (Bs - r.oy) * ivy;
+        const double z0 = (-Bs - r.oz) * ivz, z1 = (Bs - r.oz) * ivz;
+        const double te = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmin(z0, z1));
+        const double tx = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmax(z0, z1));
+        if (te > tx || tx < tmin || te > tmax) return;  // never inside the cube at a useful parameter
+        ts = te > 0 ? te : 0;
+    }
+    const float fox = (float)(r.ox + r.dx * ts), foy = (float)(r.oy + r.dy * ts), foz = (float)(r.oz + r.dz * ts);
     const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
     const float fa = __builtin_fmaf(fdx, fdx, __builtin_fmaf(fdy, fdy, fdz * fdz));
     const bool trust = (fa > 1e-30f) && (fa < 1e30f) && (__builtin_fabsf(fox) <= F.origin_bound) &&
                        (__builtin_fabsf(foy) <= F.origin_bound) && (__builtin_fabsf(foz) <= F.origin_bound);
-    const float tminf = mode ? 9.9e-5f : 9.9e-4f;
+    // node parameters are relative to the re-based origin: t' = t - ts
+    float tminf = (float)((mode ? 0.0001 : 0.001) - ts);
+    tminf -= __builtin_fabsf(tminf) * 1e-2f + 1e-6f;  // a little below tMin - ts
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
-    const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
-    float tmaxf = (float)tmax * 1.0000005f;  // >= tmax (MaxFloat64 becomes +inf)
-
+    float tmaxf = (float)(tmax - ts);
+    tmaxf += __builtin_fabsf(tmaxf) * 4.8e-7f;  // >= tmax - ts (MaxFloat64 becomes +inf)
     int sp = 0;
-    int cur = 0;  // root
+    int cur = root;
     const int DONE = 0x7fffffff;
+    uint32_t n_leaf = 0;  // PROF only: leaves this lane visited
     PH_BEGIN(SEC_BROAD)
     while (__ballot(cur != DONE) != 0) {
         // ---- descend through internal nodes until this lane sits on a leaf (or is done)
         while (cur >= 0 && cur != DONE) {
+            if (PROF) ph.lanes[SEC_NBOX]++;  // node visits (lane count)
             const BvhNode nd = nodes[cur];
             float t0a, t0b;
             bool h0, h1;
@@ -444,10 +488,12 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
         // ---- leaf: exact tests
         if (cur != DONE) {
             PH_BEGIN(SEC_NSPH)
+            if (PROF) n_leaf++;
             const uint32_t code = ~(uint32_t)cur;
             const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 const BvhObj &bo = bobjs[first + k];
+                if (PROF) ph.exec[SEC_NBOX]++;  // exact object tests (lane count)
                 const int kind = bo.o.kind & 0xff;
                 if (mode != 0 && !(bo.o.kind & 0x100)) continue;
                 const int i = bo.index;
@@ -464,7 +510,8 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                     best = i;
                     tmax = t;
                     best_is_box = is_box;
-                    tmaxf = (float)tmax * 1.0000005f;
+                    tmaxf = (float)(tmax - ts);
+                    tmaxf += __builtin_fabsf(tmaxf) * 4.8e-7f;
                 }
             }
             if (sp > 0) {
@@ -477,6 +524,27 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
         }
     }
     PH_END(SEC_BROAD)
+    if (PROF) {
+        // histogram of leaves visited per scan: bins <4, <16, <64, <256, <1024, >=1024 (closest-hit scans in
+        // the `exec` counters of three otherwise unused section ids and their `cyc` words, exit searches in `lanes`)
+        const int bin = n_leaf < 4 ? 0 : n_leaf < 16 ? 1 : n_leaf < 64 ? 2 : n_leaf < 256 ? 3 : n_leaf < 1024 ? 4 : 5;
+        if (bin == 5 && ph.dbg) {  // sample one very long traversal
+            ph.dbg[-4] = 1;
+            ph.dbg[0] = n_leaf;
+            ph.dbg[1] = ptm::to_bits(tmax);
+            ph.dbg[2] = ptm::to_bits((double)trust);
+            ph.dbg[3] = (unsigned long long)mode;
+            ph.dbg[4] = ptm::to_bits(r.ox); ph.dbg[5] = ptm::to_bits(r.oy); ph.dbg[6] = ptm::to_bits(r.oz);
+            ph.dbg[7] = ptm::to_bits(r.dx); ph.dbg[8] = ptm::to_bits(r.dy); ph.dbg[9] = ptm::to_bits(r.dz);
+        }
+        const int id = bin < 2 ? SEC_LENS : bin < 4 ? SEC_SPH_ROOT : SEC_SPH_ROOT2;
+        if (mode == 0) {
+            if (bin & 1) ph.cyc[id]++;
+            else ph.exec[id]++;
+        } else if (!(bin & 1)) {
+            ph.lanes[id]++;
+        }
+    }
 }
 
 // Ray generation pre-pass: one thread per job of the chunk, all lanes busy and neighbouring
@@ -695,7 +763,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             // -------------------------------------------------------- scan
             SEC_BEGIN(SEC_SCAN)
             const RayD ray{ox, oy, oz, dx, dy, dz};
-            const ProfHooks ph{p_exec, p_lanes, p_cyc, lane};
+            const ProfHooks ph{p_exec, p_lanes, p_cyc, lane, B.counters + 8};
             int best;
             double tmax;
             if (SCAN == SCAN_UNIFORM) {

@@ -368,6 +368,7 @@ void build_broad(const std::vector<DevObj> &world, Frame &fr) {
     F.n_plane = (int32_t)fr.plane_idx.size();
     F.broad_ok = world.size() <= 64 ? 1 : 0;
     F.origin_bound = (float)std::min(4.0 * B, 3.0e38);
+    F.scene_bound = B * (1.0 + 1.0 / 512.0);  // the inflation is B/4096
 }
 
 int32_t tiles_of_shard(int32_t ntiles, const pt_shard &sh) {
@@ -680,6 +681,7 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, std
     const bool big = scan == ptk::SCAN_BVH || scan == ptk::SCAN_VERIFY_BVH;
     fr.bvh_nodes.clear();
     fr.bvh_objs.clear();
+    F.bvh_root = F.bvh_root_exit = -1;
     if (big) {
         std::vector<int32_t> finite;
         double Bnd = 1.0;
@@ -691,16 +693,38 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, std
             for (int k = 0; k < 3; k++) Bnd = std::max(Bnd, std::max(std::fabs(bb.lo[k]), std::fabs(bb.hi[k])));
         }
         if (!(Bnd < 1e30)) Bnd = INFINITY;
-        ptbvh::Built built = ptbvh::build(world, finite, Bnd * (1.0 / 4096.0));
-        if (built.depth > PT_BVH_STACK) return fail(PT_ERR_INVALID, "BVH deeper than the traversal stack");
-        fr.bvh_depth = built.depth;
+        // two hierarchies: every finite object (closest-hit scans) and the dielectric ones only (exit
+        // searches accept nothing else, renderer.go:333, and would otherwise walk the whole line of sight)
+        std::vector<int32_t> glass;
+        for (int32_t i : finite)
+            if (world[(size_t)i].kind & 0x100) glass.push_back(i);
+        const double margin = Bnd * (1.0 / 4096.0);
+        ptbvh::Built built = ptbvh::build(world, finite, margin);
+        ptbvh::Built builtd = ptbvh::build(world, glass, margin);
+        if (built.depth > PT_BVH_STACK || builtd.depth > PT_BVH_STACK)
+            return fail(PT_ERR_INVALID, "BVH deeper than the traversal stack");
+        fr.bvh_depth = std::max(built.depth, builtd.depth);
+        const int32_t node_off = (int32_t)built.nodes.size(), obj_off = (int32_t)built.order.size();
         fr.bvh_nodes = std::move(built.nodes);
-        fr.bvh_objs.resize(built.order.size());
-        for (size_t k = 0; k < built.order.size(); k++) {
-            std::memset(&fr.bvh_objs[k], 0, sizeof(BvhObj));
-            fr.bvh_objs[k].o = world[(size_t)built.order[k]];
-            fr.bvh_objs[k].index = built.order[k];
+        for (BvhNode nd : builtd.nodes) {  // append, re-basing node indices and leaf ranges
+            auto rebase = [&](int32_t c) -> int32_t {
+                if (c >= 0) return c + node_off;
+                const uint32_t code = ~(uint32_t)c;
+                return ~(int32_t)(((code & 0x0fffffffu) + (uint32_t)obj_off) | (code & 0xf0000000u));
+            };
+            nd.c0 = rebase(nd.c0);
+            nd.c1 = rebase(nd.c1);
+            fr.bvh_nodes.push_back(nd);
         }
+        fr.bvh_objs.resize(built.order.size() + builtd.order.size());
+        for (size_t k = 0; k < fr.bvh_objs.size(); k++) {
+            const int32_t oi = k < built.order.size() ? built.order[k] : builtd.order[k - built.order.size()];
+            std::memset(&fr.bvh_objs[k], 0, sizeof(BvhObj));
+            fr.bvh_objs[k].o = world[(size_t)oi];
+            fr.bvh_objs[k].index = oi;
+        }
+        F.bvh_root_exit = builtd.nodes.empty() ? -1 : node_off;
+        F.bvh_root = fr.bvh_nodes.empty() || built.order.empty() ? -1 : 0;
     }
     F.n_bvh_nodes = (int32_t)fr.bvh_nodes.size();
     F.n_bvh_objs = (int32_t)fr.bvh_objs.size();

@@ -33,7 +33,9 @@ def make_scene(n: int, seed: int = 1, room: float = 40.0, light_every: int = 23)
         scn.Material(id="lamp", type="emissive", emit=scn.Color(1.0, 0.9, 0.7), power=12.0),
     ]
     sc.materials = mats
-    surf = ["red", "green", "blue", "gold", "chrome", "glass", "tinted", "mirror"]
+    # one object in ten is glass (the reference scenes hold 1-5 glass objects among 11-44)
+    surf = ["red", "green", "blue", "gold", "chrome", "mirror", "red", "green", "blue", "gold", "red", "green", "blue",
+            "chrome", "mirror", "red", "green", "blue", "glass", "tinted"]
     h = room * 0.5
     objs = [scn.Object(id="ground", type="plane", position=scn.Vec3(0, 0, 0), size=scn.Vec3(0, 0, 0), material_id="floor")]
     wall_t = 0.5

@@ -11,7 +11,11 @@ w, h, spp, d = (int(x) for x in (sys.argv[2:6] if len(sys.argv) >= 6 else (1920,
 SEC = ["iter", "raygen", "lens", "scan", "sph_root", "sph_root2", "hitrec", "cosine", "diel", "exitpost", "rr",
        "finish", "sky", "unitdir", "broad", "nar_sph", "nar_box", "plane"]
 ctx = capi.Context(ndev=1)
-sc = scene.load("scenes/%s.json" % name)
+if name.startswith("synth:"):
+    from path_trace_golang_amd import synth
+    sc = synth.make_scene(int(name.split(":")[1]), 1)
+else:
+    sc = scene.load("scenes/%s.json" % name)
 img = np.zeros((h, w, 4), np.uint8)
 st = hip.render(sc, hip.RenderConfig(w, h, spp, d, 1), img, ctx=ctx)
 buf = (C.c_uint64 * (3 * len(SEC)))()
@@ -22,3 +26,12 @@ print("%-10s %14s %10s %8s %12s %10s" % ("section", "wave-execs", "exec/iter", "
 for i, s in enumerate(SEC):
     e, l, c = buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]
     print("%-10s %14d %10.3f %8.1f %12.3f %10.0f" % (s, e, e / max(it_exec, 1), 100.0 * l / max(64 * e, 1), c / max(it_cyc, 1), c / max(e, 1)))
+
+if name.startswith("synth:"):
+    g = lambda i, k: buf[3 * SEC.index(i) + k]
+    print("leaves visited per closest-hit scan: <4: %d  <16: %d  <64: %d  <256: %d  <1024: %d  >=1024: %d" % (
+        g("lens", 0), g("lens", 2), g("sph_root", 0), g("sph_root", 2), g("sph_root2", 0), g("sph_root2", 2)))
+    print("exit searches (even bins only): <4: %d  [16,64): %d  [256,1024): %d" % (g("lens", 1), g("sph_root", 1), g("sph_root2", 1)))
+
+os.environ["PTCORE_VERBOSE"] = "1"
+capi.load().pt_debug_scan_mismatches(ctx.handle)
