@@ -108,6 +108,7 @@ struct Device {
     uint32_t nslots = 0;
     bool acc_started = false;
     int blocks_per_cu = 0;
+    uint64_t scene_gen = 0;  // SceneData generation resident on this device (0 = none)
 };
 
 struct Frame {
@@ -121,6 +122,20 @@ struct Frame {
     int32_t done_spp = 0;
     uint32_t chunk = 0;
     bool stats_on = false;
+    size_t lds_bytes = 0;
+    int scan = 0;  // ptk::SCAN_* used for this frame
+    std::chrono::steady_clock::time_point t0;
+};
+
+// Everything derived from the scene alone (world, broad-phase records, hierarchies).  Kept across
+// frames: an unchanged scene (progressive previews, benchmark loops, camera-only edits do not count:
+// the camera is not part of it) is neither rebuilt nor uploaded again.
+struct SceneData {
+    bool valid = false;
+    int scan_req = -2;
+    uint64_t gen = 0;
+    std::vector<DevObj> world;
+    std::vector<DevMat> mats;
     std::vector<BroadSphere> bsph;
     std::vector<BroadBox> bbox;
     std::vector<int32_t> plane_idx;
@@ -128,8 +143,8 @@ struct Frame {
     std::vector<BvhObj> bvh_objs;
     int bvh_depth = 0;
     size_t lds_bytes = 0;
-    int scan = 0;  // ptk::SCAN_* used for this frame
-    std::chrono::steady_clock::time_point t0;
+    int scan = 0;
+    DevFrame Fs{};  // the scene-dependent fields of DevFrame
 };
 
 }  // namespace
@@ -137,6 +152,7 @@ struct Frame {
 struct pt_ctx {
     std::vector<Device> devs;
     Frame frame;
+    SceneData sd;
     // device-0 gather / frame buffers for the host-memory entry points
     DevBuf<uint8_t> g_tiles_rgba;
     DevBuf<double> g_tiles_accum;
@@ -313,8 +329,8 @@ float round_down_f(double v) {
 // Conservative FP32 bounds for the broad phase.  B bounds every finite object's coordinates;
 // everything is inflated by m = B * 2^-12 (two orders of magnitude above the worst FP32 rounding of
 // the broad-phase arithmetic for ray origins inside [-4B, 4B]^3), and rounded outward.
-void build_broad(const std::vector<DevObj> &world, Frame &fr) {
-    DevFrame &F = fr.F;
+void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
+    DevFrame &F = fr.Fs;
     fr.bsph.clear();
     fr.bbox.clear();
     fr.plane_idx.clear();
@@ -419,9 +435,11 @@ int32_t dev_events(Device &d, std::vector<EventPair> &v, size_t need) {
     return PT_OK;
 }
 
-int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, const std::vector<DevMat> &mats,
-                  const pt_shard &shard, hipStream_t stream) {
+int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t stream) {
     Frame &fr = ctx->frame;
+    const SceneData &sd = ctx->sd;
+    const std::vector<DevObj> &world = sd.world;
+    const std::vector<DevMat> &mats = sd.mats;
     HIP_TRY(hipSetDevice(d.ordinal));
     d.stream = stream ? stream : d.own_stream;
     d.shard = shard;
@@ -430,28 +448,30 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const std::vector<DevObj> &world, cons
     d.acc_started = false;
     d.n_trace = d.n_resolve = 0;
     d.first_recorded = false;
-    HIP_TRY(d.objs.reserve(std::max<size_t>(1, world.size())));
-    HIP_TRY(d.mats.reserve(mats.size()));
-    if (!world.empty())
-        HIP_TRY(hipMemcpyAsync(d.objs.p, world.data(), world.size() * sizeof(DevObj), hipMemcpyHostToDevice, d.stream));
-    HIP_TRY(hipMemcpyAsync(d.mats.p, mats.data(), mats.size() * sizeof(DevMat), hipMemcpyHostToDevice, d.stream));
-    HIP_TRY(d.bsph.reserve(std::max<size_t>(1, fr.bsph.size())));
-    HIP_TRY(d.bbox.reserve(std::max<size_t>(1, fr.bbox.size())));
-    HIP_TRY(d.plane_idx.reserve(std::max<size_t>(1, fr.plane_idx.size())));
-    if (!fr.bsph.empty())
-        HIP_TRY(hipMemcpyAsync(d.bsph.p, fr.bsph.data(), fr.bsph.size() * sizeof(BroadSphere), hipMemcpyHostToDevice, d.stream));
-    if (!fr.bbox.empty())
-        HIP_TRY(hipMemcpyAsync(d.bbox.p, fr.bbox.data(), fr.bbox.size() * sizeof(BroadBox), hipMemcpyHostToDevice, d.stream));
-    if (!fr.plane_idx.empty())
-        HIP_TRY(hipMemcpyAsync(d.plane_idx.p, fr.plane_idx.data(), fr.plane_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
-    HIP_TRY(d.bvh_nodes.reserve(std::max<size_t>(1, fr.bvh_nodes.size())));
-    HIP_TRY(d.bvh_objs.reserve(std::max<size_t>(1, fr.bvh_objs.size())));
-    if (!fr.bvh_nodes.empty())
-        HIP_TRY(hipMemcpyAsync(d.bvh_nodes.p, fr.bvh_nodes.data(), fr.bvh_nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, d.stream));
-    if (!fr.bvh_objs.empty())
-        HIP_TRY(hipMemcpyAsync(d.bvh_objs.p, fr.bvh_objs.data(), fr.bvh_objs.size() * sizeof(BvhObj), hipMemcpyHostToDevice, d.stream));
-    // the copies above read pageable host vectors that die with the caller's scope
-    HIP_TRY(hipStreamSynchronize(d.stream));
+    if (d.scene_gen != sd.gen) {
+        HIP_TRY(d.objs.reserve(std::max<size_t>(1, world.size())));
+        HIP_TRY(d.mats.reserve(mats.size()));
+        if (!world.empty())
+            HIP_TRY(hipMemcpyAsync(d.objs.p, world.data(), world.size() * sizeof(DevObj), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipMemcpyAsync(d.mats.p, mats.data(), mats.size() * sizeof(DevMat), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(d.bsph.reserve(std::max<size_t>(1, sd.bsph.size())));
+        HIP_TRY(d.bbox.reserve(std::max<size_t>(1, sd.bbox.size())));
+        HIP_TRY(d.plane_idx.reserve(std::max<size_t>(1, sd.plane_idx.size())));
+        if (!sd.bsph.empty())
+            HIP_TRY(hipMemcpyAsync(d.bsph.p, sd.bsph.data(), sd.bsph.size() * sizeof(BroadSphere), hipMemcpyHostToDevice, d.stream));
+        if (!sd.bbox.empty())
+            HIP_TRY(hipMemcpyAsync(d.bbox.p, sd.bbox.data(), sd.bbox.size() * sizeof(BroadBox), hipMemcpyHostToDevice, d.stream));
+        if (!sd.plane_idx.empty())
+            HIP_TRY(hipMemcpyAsync(d.plane_idx.p, sd.plane_idx.data(), sd.plane_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(d.bvh_nodes.reserve(std::max<size_t>(1, sd.bvh_nodes.size())));
+        HIP_TRY(d.bvh_objs.reserve(std::max<size_t>(1, sd.bvh_objs.size())));
+        if (!sd.bvh_nodes.empty())
+            HIP_TRY(hipMemcpyAsync(d.bvh_nodes.p, sd.bvh_nodes.data(), sd.bvh_nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, d.stream));
+        if (!sd.bvh_objs.empty())
+            HIP_TRY(hipMemcpyAsync(d.bvh_objs.p, sd.bvh_objs.data(), sd.bvh_objs.size() * sizeof(BvhObj), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        d.scene_gen = sd.gen;
+    }
     HIP_TRY(d.queue.reserve(1));
     HIP_TRY(d.counters.reserve(24));
     HIP_TRY(hipMemsetAsync(d.counters.p, 0, 24 * sizeof(unsigned long long), d.stream));
@@ -645,51 +665,45 @@ int32_t dev_collect(Device &d, pt_stats *st, int slot) {
     return PT_OK;
 }
 
-int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, std::vector<DevObj> &world,
-                   std::vector<DevMat> &mats, uint32_t max_slots) {
-    Frame &fr = ctx->frame;
-    fr = Frame();
-    fr.cfg = *cfg;
+// (Re)builds ctx->sd when the scene or the requested scan strategy changed.
+int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
+    SceneData &sd = ctx->sd;
+    std::vector<DevObj> world;
+    std::vector<DevMat> mats;
     scene_to_world(*scene, world, mats);
-    fr.nobj = (int32_t)world.size();
-    fr.nmat = (int32_t)mats.size();
-    fr.cam = new_camera(scene->camera, cfg->width, cfg->height);
-    fr.sky = make_sky(scene->sky);
-    fr.ntx = (cfg->width + 31) / 32;
-    fr.nty = (cfg->height + 31) / 32;
-    fr.stats_on = (cfg->flags & PT_FLAG_PIXEL_STATS) != 0;
-    DevFrame &F = fr.F;
+    const bool same = sd.valid && sd.scan_req == ctx->scan_mode && world.size() == sd.world.size() &&
+                      mats.size() == sd.mats.size() &&
+                      (world.empty() || std::memcmp(world.data(), sd.world.data(), world.size() * sizeof(DevObj)) == 0) &&
+                      std::memcmp(mats.data(), sd.mats.data(), mats.size() * sizeof(DevMat)) == 0;
+    if (same) return PT_OK;
+    sd.valid = false;
+    sd.world = std::move(world);
+    sd.mats = std::move(mats);
+    sd.scan_req = ctx->scan_mode;
+    DevFrame &F = sd.Fs;
     std::memset(&F, 0, sizeof F);
-    F.width = cfg->width;
-    F.height = cfg->height;
-    F.max_depth = cfg->max_depth;
-    F.nobj = fr.nobj;
-    F.nmat = fr.nmat;
-    F.ntx = fr.ntx;
-    F.nty = fr.nty;
-    F.seed_key = ptm::seed_key(cfg->seed);
-    F.inv_width = 1.0 / (double)(cfg->width - 1);
-    F.inv_height = 1.0 / (double)(cfg->height - 1);
-    F.height_m1 = (double)(cfg->height - 1);
-    build_broad(world, fr);
+    F.nobj = (int32_t)sd.world.size();
+    F.nmat = (int32_t)sd.mats.size();
+    build_broad(sd.world, sd);
     // closest-hit strategy: <= 64 objects -> candidate bitmask; more -> BVH.  PTCORE_SCAN overrides.
     int scan = ctx->scan_mode;
     if (scan < 0) scan = F.broad_ok ? ptk::SCAN_BROAD : ptk::SCAN_BVH;
     if ((scan == ptk::SCAN_BROAD || scan == ptk::SCAN_VERIFY) && !F.broad_ok)
         scan = scan == ptk::SCAN_VERIFY ? ptk::SCAN_VERIFY_BVH : ptk::SCAN_BVH;
-    fr.scan = scan;
+    sd.scan = scan;
     const bool big = scan == ptk::SCAN_BVH || scan == ptk::SCAN_VERIFY_BVH;
-    fr.bvh_nodes.clear();
-    fr.bvh_objs.clear();
+    sd.bvh_nodes.clear();
+    sd.bvh_objs.clear();
     F.bvh_root = F.bvh_root_exit = -1;
+    const std::vector<DevObj> &w = sd.world;
     if (big) {
         std::vector<int32_t> finite;
         double Bnd = 1.0;
-        for (size_t i = 0; i < world.size(); i++) {
-            const int kind = world[i].kind & 0xff;
+        for (size_t i = 0; i < w.size(); i++) {
+            const int kind = w[i].kind & 0xff;
             if (kind == KIND_PLANE) continue;
             finite.push_back((int32_t)i);
-            const ptbvh::Aabb bb = ptbvh::object_bounds(world[i]);
+            const ptbvh::Aabb bb = ptbvh::object_bounds(w[i]);
             for (int k = 0; k < 3; k++) Bnd = std::max(Bnd, std::max(std::fabs(bb.lo[k]), std::fabs(bb.hi[k])));
         }
         if (!(Bnd < 1e30)) Bnd = INFINITY;
@@ -697,15 +711,15 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, std
         // searches accept nothing else, renderer.go:333, and would otherwise walk the whole line of sight)
         std::vector<int32_t> glass;
         for (int32_t i : finite)
-            if (world[(size_t)i].kind & 0x100) glass.push_back(i);
+            if (w[(size_t)i].kind & 0x100) glass.push_back(i);
         const double margin = Bnd * (1.0 / 4096.0);
-        ptbvh::Built built = ptbvh::build(world, finite, margin);
-        ptbvh::Built builtd = ptbvh::build(world, glass, margin);
+        ptbvh::Built built = ptbvh::build(w, finite, margin);
+        ptbvh::Built builtd = ptbvh::build(w, glass, margin);
         if (built.depth > PT_BVH_STACK || builtd.depth > PT_BVH_STACK)
             return fail(PT_ERR_INVALID, "BVH deeper than the traversal stack");
-        fr.bvh_depth = std::max(built.depth, builtd.depth);
+        sd.bvh_depth = std::max(built.depth, builtd.depth);
         const int32_t node_off = (int32_t)built.nodes.size(), obj_off = (int32_t)built.order.size();
-        fr.bvh_nodes = std::move(built.nodes);
+        sd.bvh_nodes = std::move(built.nodes);
         for (BvhNode nd : builtd.nodes) {  // append, re-basing node indices and leaf ranges
             auto rebase = [&](int32_t c) -> int32_t {
                 if (c >= 0) return c + node_off;
@@ -714,25 +728,56 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, std
             };
             nd.c0 = rebase(nd.c0);
             nd.c1 = rebase(nd.c1);
-            fr.bvh_nodes.push_back(nd);
+            sd.bvh_nodes.push_back(nd);
         }
-        fr.bvh_objs.resize(built.order.size() + builtd.order.size());
-        for (size_t k = 0; k < fr.bvh_objs.size(); k++) {
+        sd.bvh_objs.resize(built.order.size() + builtd.order.size());
+        for (size_t k = 0; k < sd.bvh_objs.size(); k++) {
             const int32_t oi = k < built.order.size() ? built.order[k] : builtd.order[k - built.order.size()];
-            std::memset(&fr.bvh_objs[k], 0, sizeof(BvhObj));
-            fr.bvh_objs[k].o = world[(size_t)oi];
-            fr.bvh_objs[k].index = oi;
+            std::memset(&sd.bvh_objs[k], 0, sizeof(BvhObj));
+            sd.bvh_objs[k].o = w[(size_t)oi];
+            sd.bvh_objs[k].index = oi;
         }
         F.bvh_root_exit = builtd.nodes.empty() ? -1 : node_off;
-        F.bvh_root = fr.bvh_nodes.empty() || built.order.empty() ? -1 : 0;
+        F.bvh_root = sd.bvh_nodes.empty() || built.order.empty() ? -1 : 0;
     }
-    F.n_bvh_nodes = (int32_t)fr.bvh_nodes.size();
-    F.n_bvh_objs = (int32_t)fr.bvh_objs.size();
+    F.n_bvh_nodes = (int32_t)sd.bvh_nodes.size();
+    F.n_bvh_objs = (int32_t)sd.bvh_objs.size();
     F.world_in_lds = big ? 0 : 1;
-    fr.lds_bytes = big ? (size_t)PT_BVH_STACK * PT_BLOCK * sizeof(int)
-                       : (size_t)fr.nobj * sizeof(DevObj) + (size_t)fr.nmat * sizeof(DevMat);
-    if (fr.lds_bytes > 160 * 1024)
+    sd.lds_bytes = big ? (size_t)PT_BVH_STACK * PT_BLOCK * sizeof(int)
+                       : (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat);
+    if (sd.lds_bytes > 160 * 1024)
         return fail(PT_ERR_INVALID, "scene does not fit the 160 KiB LDS of a CU with this scan strategy (use the BVH: unset PTCORE_SCAN)");
+    sd.gen++;
+    sd.valid = true;
+    return PT_OK;
+}
+
+int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uint32_t max_slots) {
+    if (int32_t rc = scene_prepare(ctx, scene)) return rc;
+    const SceneData &sd = ctx->sd;
+    Frame &fr = ctx->frame;
+    fr = Frame();
+    fr.cfg = *cfg;
+    fr.nobj = sd.Fs.nobj;
+    fr.nmat = sd.Fs.nmat;
+    fr.scan = sd.scan;
+    fr.lds_bytes = sd.lds_bytes;
+    fr.cam = new_camera(scene->camera, cfg->width, cfg->height);
+    fr.sky = make_sky(scene->sky);
+    fr.ntx = (cfg->width + 31) / 32;
+    fr.nty = (cfg->height + 31) / 32;
+    fr.stats_on = (cfg->flags & PT_FLAG_PIXEL_STATS) != 0;
+    DevFrame &F = fr.F;
+    F = sd.Fs;
+    F.width = cfg->width;
+    F.height = cfg->height;
+    F.max_depth = cfg->max_depth;
+    F.ntx = fr.ntx;
+    F.nty = fr.nty;
+    F.seed_key = ptm::seed_key(cfg->seed);
+    F.inv_width = 1.0 / (double)(cfg->width - 1);
+    F.inv_height = 1.0 / (double)(cfg->height - 1);
+    F.height_m1 = (double)(cfg->height - 1);
     // chunk of samples per pass: bounded by the L budget and by 2^31 jobs
     uint32_t chunk = cfg->spp_chunk > 0 ? (uint32_t)cfg->spp_chunk : 0;
     const uint32_t slots = std::max(1u, max_slots);
@@ -956,12 +1001,10 @@ int32_t pt_begin(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg) {
     if (ctx->frame.open) return fail(PT_ERR_STATE, "pt_begin: a frame is already open");
     const int32_t ndev = (int32_t)ctx->devs.size();
     const int32_t ntiles = ((cfg->width + 31) / 32) * ((cfg->height + 31) / 32);
-    std::vector<DevObj> world;
-    std::vector<DevMat> mats;
     const uint32_t max_slots = (uint32_t)tiles_of_shard(ntiles, pt_shard{0, ndev}) * 1024u;
-    if (int32_t rc = frame_open(ctx, scene, cfg, world, mats, max_slots)) return rc;
+    if (int32_t rc = frame_open(ctx, scene, cfg, max_slots)) return rc;
     for (int32_t i = 0; i < ndev; i++) {
-        if (int32_t rc = dev_begin(ctx, ctx->devs[(size_t)i], world, mats, pt_shard{i, ndev}, nullptr)) {
+        if (int32_t rc = dev_begin(ctx, ctx->devs[(size_t)i], pt_shard{i, ndev}, nullptr)) {
             ctx->frame.open = false;
             return rc;
         }
@@ -1129,13 +1172,11 @@ int32_t pt_render_tiles_device(pt_ctx *ctx, const pt_scene *scene, const pt_conf
     if (sh.count <= 0 || sh.index < 0 || sh.index >= sh.count) return fail(PT_ERR_INVALID, "bad shard");
     if (cfg->flags & PT_FLAG_PIXEL_STATS) return fail(PT_ERR_INVALID, "pixel stats are not available on the device entry point");
     const int32_t ntiles = ((cfg->width + 31) / 32) * ((cfg->height + 31) / 32);
-    std::vector<DevObj> world;
-    std::vector<DevMat> mats;
     const uint32_t slots = (uint32_t)tiles_of_shard(ntiles, sh) * 1024u;
-    if (int32_t rc = frame_open(ctx, scene, cfg, world, mats, slots)) return rc;
+    if (int32_t rc = frame_open(ctx, scene, cfg, slots)) return rc;
     Frame &fr = ctx->frame;
     Device &d = ctx->devs[0];
-    int32_t rc = dev_begin(ctx, d, world, mats, sh, static_cast<hipStream_t>(stream));
+    int32_t rc = dev_begin(ctx, d, sh, static_cast<hipStream_t>(stream));
     for (int32_t s = 0; rc == PT_OK && s < cfg->samples_per_px;) {
         const uint32_t S = std::min<uint32_t>((uint32_t)(cfg->samples_per_px - s), fr.chunk);
         rc = dev_step(ctx, d, (uint32_t)s, S);
