@@ -90,14 +90,23 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: torch.cuda.is_available() is False", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks: every rank
+    # renders on GPU (local_rank mod visible GPUs) and the tile gather goes through host memory.  The
+    # default, and what the driver runs, is "nccl" = RCCL over xGMI with one GPU per rank.
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    ngpu = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, ngpu)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     capi.load()
     L = capi.load()
-    ctx = capi.Context(devices=[local_rank])
+    ctx = capi.Context(devices=[dev_index])
     sc = scene.load(os.path.join(ROOT, "scenes", args.scene + ".json"))
     flat = hip.FlatScene(sc)
     cfg = hip.pt_config(hip.RenderConfig(args.width, args.height, args.spp, args.depth, args.seed, args.spp_chunk, 0))
@@ -135,7 +144,13 @@ def main() -> int:
         capi.check(L.pt_render_tiles_device(ctx.handle, C.byref(flat.c), C.byref(cfg), C.byref(shard),
                                             C.c_void_p(tiles.data_ptr()), None, C.c_void_p(stream.cuda_stream),
                                             C.byref(st)))
-        distributed.assemble_frame(tiles, W, H, rank, world, untile, scratch)
+        if backend == "nccl" or world == 1:
+            distributed.assemble_frame(tiles, W, H, rank, world, untile, scratch)
+        else:  # rehearsal: gather through host memory
+            host = tiles.cpu()
+            bufs = distributed.gather_tiles(host, rank, world)
+            if rank == 0:
+                untile([b.to(dev) for b in bufs], stride_tiles)
         return st
 
     def fence():
@@ -151,9 +166,10 @@ def main() -> int:
     fence()
     elapsed = time.perf_counter() - t0
 
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     tot = torch.tensor([float(sum(s.segments for s in stats)), float(sum(s.samples for s in stats)),
-                        float(sum(s.exit_scans for s in stats))], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                        float(sum(s.exit_scans for s in stats))], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -176,7 +192,9 @@ def main() -> int:
         achieved_gbs = alg_bytes / max(avg_launch_s, 1e-12) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        default_cfg = (world == 1 and args.scene == "gpu_showcase" and (W, H, args.spp, args.depth) == (1920, 1080, 1024, 8)
+                       and args.spp_chunk == 0)
+        if os.path.exists(tpath) and default_cfg:  # the PMC passes were taken on exactly this launch shape
             try:
                 with open(tpath) as f:
                     traffic = json.load(f).get("trace_kernel", {}).get("hbm_bytes_per_launch")
@@ -204,7 +222,7 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": "scenes/%s.json %dx%d, %d spp, max depth %d, seed %d (BASELINE config 4)"
                                    % (args.scene, W, H, args.spp, args.depth, args.seed),
-                       "tiles": "32x32 interleaved over %d rank(s)" % world, "gather": "rccl" if world > 1 else "none",
+                       "tiles": "32x32 interleaved over %d rank(s)" % world, "gather": ("rccl" if backend == "nccl" else backend + " (rehearsal)") if world > 1 else "none",
                        "spp_chunk": chunk},
             "primary_msamples_per_s": samples / elapsed / 1e6,
             "segments_per_sample": segments / max(samples, 1.0),
