@@ -97,7 +97,7 @@ enum { SEC_ITER = 0, SEC_RAYGEN, SEC_LENS, SEC_SCAN, SEC_SPH_ROOT, SEC_SPH_ROOT2
 
 
 enum { SCAN_UNIFORM = 0, SCAN_BROAD = 1, SCAN_VERIFY = 2, SCAN_BVH = 3, SCAN_VERIFY_BVH = 4 };
-#define PT_BVH_STACK 48
+#define PT_BVH_STACK 32
 
 // Diagnostic hooks handed to the scan routines (all no-ops unless PROF).
 struct ProfHooks {
