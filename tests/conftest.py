@@ -35,8 +35,9 @@ def gpu_ctx():
     # libptcore.so is loaded, so both share one HIP runtime (the loader matches the SONAME)
     import torch  # noqa: F401
 
-    from path_trace_golang_amd import capi
+    from path_trace_golang_amd import build, capi
 
+    build.build_all()  # no-op when the in-tree artefacts are current (hipcc exists on the GPU box too)
     capi.load()
     if capi.device_count() < 1:
         pytest.fail("no HIP device visible: the gpu-marked tests must run on the GPU box")
