@@ -120,10 +120,9 @@ struct DevFrame {
     int32_t bvh_root;                 // root node of the hierarchy over every finite object, -1 if none
     int32_t bvh_root_exit;            // root of the hierarchy over dielectric objects only, -1 if none
     int32_t pad_i;
-    int32_t broad_ok;    // 1: nobj <= 64 and every finite object has finite bounds -> broad/narrow scan usable
-    uint64_t all_mask;   // bit i set for every object i
-    uint64_t diel_mask;  // objects whose material is dielectric
-    uint64_t sphere_mask, box_mask;
+    int32_t broad_ok;    // 1: at most 32 sphere records and 32 box records -> candidate-bitmask scan usable
+    uint32_t sph_all, box_all;    // (1 << n_bsph) - 1, (1 << n_bbox) - 1
+    uint32_t sph_diel, box_diel;  // records whose object is dielectric (exit searches)
     float origin_bound;  // rays whose origin leaves [-origin_bound, origin_bound]^3 keep every candidate
     float pad_f;
     double scene_bound;  // Bs: every finite object (inflated) lies inside [-Bs, Bs]^3

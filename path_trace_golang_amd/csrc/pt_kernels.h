@@ -238,8 +238,8 @@ __device__ __forceinline__ bool wins(int mode, bool is_box, int i, double t, int
 // Broad phase in FP32 over inflated bounds + exact FP64 narrow phase over the survivors.
 template <bool PROF, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
 __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_obj, SphPtr g_bs, BoxPtr g_bb, IdxPtr g_pl,
-                                                  const DevObj *s_obj, const RayD &r, int mode, int &best, double &tmax,
-                                                  const ProfHooks &ph) {
+                                                  const DevObj *s_obj, const int *s_kidx, const RayD &r, int mode, int &best,
+                                                  double &tmax, const ProfHooks &ph) {
     const double tmin = mode ? 0.0001 : 0.001;
     tmax = ptm::max_float64();
     best = -1;
@@ -295,7 +295,9 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     float tminf = (float)(tmin - ts);  // FP32 parameters are relative to the entry point
     tminf -= __builtin_fabsf(tminf) * 1e-2f + 1e-6f;  // a little below tMin - ts
     const float inv_a = __builtin_amdgcn_rcpf(fa);
-    uint32_t clo = 0, chi = 0;
+    // candidate masks: bit k of `cs` = k-th sphere record, bit k of `cb` = k-th box record (<= 32 of each;
+    // the bit is wave-uniform, so setting it costs one select and one or)
+    uint32_t cs = 0, cb = 0;
     for (int k = 0; k < F.n_bsph; k++) {
         const auto &s = g_bs[k];
         const float ocx = fox - s.cx, ocy = foy - s.cy, ocz = foz - s.cz;
@@ -306,9 +308,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         const float rem = s.rm2 - d2;  // >= 0: the line passes within the inflated radius
         const float u = tminf - tca;   // > 0: closest approach lies before tMin
         const bool miss = (rem < 0.0f) || ((u > 0.0f) && (u * u * fa > rem));  // outside, or wholly behind
-        const uint32_t bit = 1u << (s.index & 31);
-        if (s.index < 32) clo |= miss ? 0u : bit;
-        else chi |= miss ? 0u : bit;
+        cs |= miss ? 0u : (1u << k);
     }
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
     for (int k = 0; k < F.n_bbox; k++) {
@@ -322,22 +322,19 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
                                          __builtin_fmaxf(taz, tbz));
         const bool miss = t1 < t0;
-        const uint32_t bit = 1u << (bx.index & 31);
-        if (bx.index < 32) clo |= miss ? 0u : bit;
-        else chi |= miss ? 0u : bit;
+        cb |= miss ? 0u : (1u << k);
     }
-    uint64_t cand = ((uint64_t)chi << 32) | clo;
-    if (!trust) cand = F.sphere_mask | F.box_mask;
-    if (outside_all) cand = 0;
-    if (mode != 0) cand &= F.diel_mask;
+    if (!trust) { cs = F.sph_all; cb = F.box_all; }
+    if (outside_all) { cs = 0; cb = 0; }
+    if (mode != 0) { cs &= F.sph_diel; cb &= F.box_diel; }
     PH_END(SEC_BROAD)
 
     // ---- narrow phase: spheres, then boxes, each lane on its own candidates (index order)
-    uint64_t ms = cand & F.sphere_mask;
+    uint32_t ms = cs;
     while (__ballot(ms != 0) != 0) {
         if (ms != 0) {
             PH_BEGIN(SEC_NSPH)
-            const int i = __builtin_ctzll(ms);
+            const int i = s_kidx[__builtin_ctz(ms)];  // record -> object index; records are in file order
             ms &= ms - 1;
             const DevObj &o = s_obj[i];
             double t = 0;
@@ -352,13 +349,13 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
             PH_END(SEC_NSPH)
         }
     }
-    uint64_t mb = cand & F.box_mask;
+    uint32_t mb = cb;
     if (__ballot(mb != 0) != 0) {
         const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
         while (__ballot(mb != 0) != 0) {
             if (mb != 0) {
                 PH_BEGIN(SEC_NBOX)
-                const int i = __builtin_ctzll(mb);
+                const int i = s_kidx[F.n_bsph + __builtin_ctz(mb)];
                 mb &= mb - 1;
                 const DevObj &o = s_obj[i];
                 double t = 0;
@@ -639,6 +636,8 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
     DevObj *lds_obj = reinterpret_cast<DevObj *>(smem);
     DevMat *lds_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
     int *lds_stack = reinterpret_cast<int *>(smem);
+    // object index of every broad-phase record (spheres, then boxes), for the per-lane narrow phase
+    int *lds_kidx = reinterpret_cast<int *>(smem + (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat));
     if (!BIG) {
         const uint64_t *g0 = reinterpret_cast<const uint64_t *>(B.objs);
         uint64_t *l0 = reinterpret_cast<uint64_t *>(lds_obj);
@@ -648,6 +647,10 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         uint64_t *l1 = reinterpret_cast<uint64_t *>(lds_mat);
         const int n1 = F.nmat * (int)(sizeof(DevMat) / 8);
         for (int i = threadIdx.x; i < n1; i += PT_BLOCK) l1[i] = g1[i];
+        if (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY) {
+            for (int i = threadIdx.x; i < F.n_bsph; i += PT_BLOCK) lds_kidx[i] = B.bsph[i].index;
+            for (int i = threadIdx.x; i < F.n_bbox; i += PT_BLOCK) lds_kidx[F.n_bsph + i] = B.bbox[i].index;
+        }
         __syncthreads();
     }
     const DevObj *const s_obj = BIG ? B.objs : lds_obj;
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
                                   (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100);
                 if (__ballot(!tame) != 0) scan_uniform(F, g_obj, ray, mode, best, tmax);
-                else scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, ray, mode, best, tmax, ph);
+                else scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, mode, best, tmax, ph);
             } else if (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) {
                 const double a_ = dx * dx + dy * dy + dz * dz;
                 const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             } else {
                 int best2;
                 double tmax2;
-                scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, ray, mode, best2, tmax2, ph);
+                scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, mode, best2, tmax2, ph);
                 scan_uniform(F, g_obj, ray, mode, best, tmax);
                 const double a_ = dx * dx + dy * dy + dz * dz;
                 const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&

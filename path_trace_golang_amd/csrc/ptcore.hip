@@ -334,7 +334,7 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     fr.bsph.clear();
     fr.bbox.clear();
     fr.plane_idx.clear();
-    F.all_mask = F.diel_mask = F.sphere_mask = F.box_mask = 0;
+    F.sph_all = F.box_all = F.sph_diel = F.box_diel = 0;
     double B = 1.0;
     for (const DevObj &o : world) {
         const int kind = o.kind & 0xff;
@@ -349,13 +349,6 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     for (size_t i = 0; i < world.size(); i++) {
         const DevObj &o = world[i];
         const int kind = o.kind & 0xff;
-        if (i < 64) {
-            const uint64_t bit = 1ull << i;
-            F.all_mask |= bit;
-            if (o.kind & 0x100) F.diel_mask |= bit;
-            if (kind == KIND_SPHERE) F.sphere_mask |= bit;
-            if (kind == KIND_BOX) F.box_mask |= bit;
-        }
         if (kind == KIND_SPHERE) {
             BroadSphere s;
             std::memset(&s, 0, sizeof s);
@@ -364,6 +357,7 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
             s.rm2 = round_up_f(rm * rm);
             if (!(s.rm2 == s.rm2)) s.rm2 = INFINITY;
             s.index = (int32_t)i;
+            if (fr.bsph.size() < 32 && (o.kind & 0x100)) F.sph_diel |= 1u << fr.bsph.size();
             fr.bsph.push_back(s);
         } else if (kind == KIND_BOX) {
             BroadBox b;
@@ -374,6 +368,7 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
                 b.hi[k] = (hi == hi) ? round_up_f(hi) : INFINITY;
             }
             b.index = (int32_t)i;
+            if (fr.bbox.size() < 32 && (o.kind & 0x100)) F.box_diel |= 1u << fr.bbox.size();
             fr.bbox.push_back(b);
         } else {
             fr.plane_idx.push_back((int32_t)i);
@@ -382,7 +377,9 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     F.n_bsph = (int32_t)fr.bsph.size();
     F.n_bbox = (int32_t)fr.bbox.size();
     F.n_plane = (int32_t)fr.plane_idx.size();
-    F.broad_ok = world.size() <= 64 ? 1 : 0;
+    F.broad_ok = (fr.bsph.size() <= 32 && fr.bbox.size() <= 32) ? 1 : 0;
+    F.sph_all = fr.bsph.size() >= 32 ? 0xffffffffu : ((1u << fr.bsph.size()) - 1u);
+    F.box_all = fr.bbox.size() >= 32 ? 0xffffffffu : ((1u << fr.bbox.size()) - 1u);
     F.origin_bound = (float)std::min(4.0 * B, 3.0e38);
     F.scene_bound = B * (1.0 + 1.0 / 512.0);  // the inflation is B/4096
 }
@@ -744,7 +741,8 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     F.n_bvh_objs = (int32_t)sd.bvh_objs.size();
     F.world_in_lds = big ? 0 : 1;
     sd.lds_bytes = big ? (size_t)PT_BVH_STACK * PT_BLOCK * sizeof(int)
-                       : (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat);
+                       : (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
+                             (size_t)(sd.bsph.size() + sd.bbox.size()) * sizeof(int);
     if (sd.lds_bytes > 160 * 1024)
         return fail(PT_ERR_INVALID, "scene does not fit the 160 KiB LDS of a CU with this scan strategy (use the BVH: unset PTCORE_SCAN)");
     sd.gen++;
