@@ -308,7 +308,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         const float rem = s.rm2 - d2;  // >= 0: the line passes within the inflated radius
         const float u = tminf - tca;   // > 0: closest approach lies before tMin
         const bool miss = (rem < 0.0f) || ((u > 0.0f) && (u * u * fa > rem));  // outside, or wholly behind
-        cs |= miss ? 0u : (1u << k);
+        cs = miss ? cs : (cs | (1u << k));
     }
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
     for (int k = 0; k < F.n_bbox; k++) {
@@ -322,7 +322,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
                                          __builtin_fmaxf(taz, tbz));
         const bool miss = t1 < t0;
-        cb |= miss ? 0u : (1u << k);
+        cb = miss ? cb : (cb | (1u << k));
     }
     if (!trust) { cs = F.sph_all; cb = F.box_all; }
     if (outside_all) { cs = 0; cb = 0; }
@@ -338,14 +338,13 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
             ms &= ms - 1;
             const DevObj &o = s_obj[i];
             double t = 0;
-            if (sphere_exact(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, tmin, tmax, t)) {
-                if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
-                              : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_SPHERE, r, t))) {
-                    best = i;
-                    tmax = t;
-                    best_is_box = false;
-                }
-            }
+            bool acc = sphere_exact(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, tmin, tmax, t) &&
+                       wins(mode, false, i, t, best, best_is_box, tmax);
+            if (acc && mode != 0) acc = exit_candidate_ok(o, KIND_SPHERE, r, t);
+            // selects, not branches: the update is four v_cndmask
+            best = acc ? i : best;
+            tmax = acc ? t : tmax;
+            best_is_box = acc ? false : best_is_box;
             PH_END(SEC_NSPH)
         }
     }
@@ -360,14 +359,12 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
                 const DevObj &o = s_obj[i];
                 double t = 0;
                 // the range is left open at the top here: `wins` compares t with tmax (strictly for a box)
-                if (box_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t)) {
-                    if (mode == 0 ? wins(0, true, i, t, best, best_is_box, tmax)
-                                  : (wins(1, true, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_BOX, r, t))) {
-                        best = i;
-                        tmax = t;
-                        best_is_box = true;
-                    }
-                }
+                bool acc = box_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t) &&
+                           wins(mode, true, i, t, best, best_is_box, tmax);
+                if (acc && mode != 0) acc = exit_candidate_ok(o, KIND_BOX, r, t);
+                best = acc ? i : best;
+                tmax = acc ? t : tmax;
+                best_is_box = acc ? true : best_is_box;
                 PH_END(SEC_NBOX)
             }
         }
