@@ -97,7 +97,7 @@ enum { SEC_ITER = 0, SEC_RAYGEN, SEC_LENS, SEC_SCAN, SEC_SPH_ROOT, SEC_SPH_ROOT2
 
 
 enum { SCAN_UNIFORM = 0, SCAN_BROAD = 1, SCAN_VERIFY = 2, SCAN_BVH = 3, SCAN_VERIFY_BVH = 4 };
-#define PT_BVH_STACK 32
+#define PT_BVH_STACK 48  // upper bound of the depth-sized per-lane stack
 
 // Diagnostic hooks handed to the scan routines (all no-ops unless PROF).
 struct ProfHooks {
@@ -375,6 +375,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
 // objects get the exact test; `wins` makes the result independent of that order.
 template <bool PROF, typename ObjPtr, typename IdxPtr>
 __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr g_pl, const BvhNode *__restrict__ nodes,
+                                         const BvhNode *lds_nodes /* nodes[0 .. F.bvh_lds_nodes) staged in LDS */,
                                          const BvhObj *__restrict__ bobjs, int *stack /* this lane's column, stride PT_BLOCK */,
                                          const RayD &r, int mode, int &best, double &tmax, const ProfHooks &ph) {
     const double tmin = mode ? 0.0001 : 0.001;
@@ -439,7 +440,9 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
         // ---- descend through internal nodes until this lane sits on a leaf (or is done)
         while (cur >= 0 && cur != DONE) {
             if (PROF) ph.lanes[SEC_NBOX]++;  // node visits (lane count)
-            const BvhNode nd = nodes[cur];
+            BvhNode nd;
+            if (cur < F.bvh_lds_nodes) nd = lds_nodes[cur];  // top of the tree: LDS packet
+            else nd = nodes[cur];                            // below: HBM / L2
             float t0a, t0b;
             bool h0, h1;
             {
@@ -633,6 +636,14 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
     DevObj *lds_obj = reinterpret_cast<DevObj *>(smem);
     DevMat *lds_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
     int *lds_stack = reinterpret_cast<int *>(smem);
+    BvhNode *lds_nodes = reinterpret_cast<BvhNode *>(smem + (size_t)F.bvh_stack * PT_BLOCK * sizeof(int));
+    if (BIG) {
+        const uint64_t *gsrc = reinterpret_cast<const uint64_t *>(B.bvh_nodes);
+        uint64_t *ldst = reinterpret_cast<uint64_t *>(lds_nodes);
+        const int nw = F.bvh_lds_nodes * (int)(sizeof(BvhNode) / 8);
+        for (int i = threadIdx.x; i < nw; i += PT_BLOCK) ldst[i] = gsrc[i];
+        __syncthreads();
+    }
     // object index of every broad-phase record (spheres, then boxes), for the per-lane narrow phase
     int *lds_kidx = reinterpret_cast<int *>(smem + (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat));
     if (!BIG) {
@@ -785,7 +796,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 if (__ballot(!tame) != 0) {
                     scan_uniform(F, g_obj, ray, mode, best, tmax);
                 } else {
-                    scan_bvh<PROF>(F, g_obj, g_pl, B.bvh_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, mode, best, tmax, ph);
+                    scan_bvh<PROF>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, mode, best, tmax, ph);
                     if (SCAN == SCAN_VERIFY_BVH) {
                         int best2;
                         double tmax2;

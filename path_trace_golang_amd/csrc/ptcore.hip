@@ -712,10 +712,33 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
         const double margin = Bnd * (1.0 / 4096.0);
         ptbvh::Built built = ptbvh::build(w, finite, margin);
         ptbvh::Built builtd = ptbvh::build(w, glass, margin);
-        if (built.depth > PT_BVH_STACK || builtd.depth > PT_BVH_STACK)
+        if (built.depth >= PT_BVH_STACK || builtd.depth >= PT_BVH_STACK)
             return fail(PT_ERR_INVALID, "BVH deeper than the traversal stack");
+        {
+            // breadth-first node order for the main tree: its top levels become one contiguous packet
+            // that every block stages in LDS (the builder emits depth-first order)
+            const std::vector<BvhNode> &src = built.nodes;
+            std::vector<int32_t> order, where(src.size(), -1);
+            order.reserve(src.size());
+            if (!src.empty()) order.push_back(0);
+            for (size_t q = 0; q < order.size(); q++) {
+                const BvhNode &nd = src[(size_t)order[q]];
+                if (nd.c0 >= 0) order.push_back(nd.c0);
+                if (nd.c1 >= 0) order.push_back(nd.c1);
+            }
+            for (size_t q = 0; q < order.size(); q++) where[(size_t)order[q]] = (int32_t)q;
+            std::vector<BvhNode> bfs(order.size());
+            for (size_t q = 0; q < order.size(); q++) {
+                BvhNode nd = src[(size_t)order[q]];
+                if (nd.c0 >= 0) nd.c0 = where[(size_t)nd.c0];
+                if (nd.c1 >= 0) nd.c1 = where[(size_t)nd.c1];
+                bfs[q] = nd;
+            }
+            built.nodes.swap(bfs);
+        }
         sd.bvh_depth = std::max(built.depth, builtd.depth);
         const int32_t node_off = (int32_t)built.nodes.size(), obj_off = (int32_t)built.order.size();
+        F.bvh_main_nodes = node_off;
         sd.bvh_nodes = std::move(built.nodes);
         for (BvhNode nd : builtd.nodes) {  // append, re-basing node indices and leaf ranges
             auto rebase = [&](int32_t c) -> int32_t {
@@ -740,7 +763,14 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     F.n_bvh_nodes = (int32_t)sd.bvh_nodes.size();
     F.n_bvh_objs = (int32_t)sd.bvh_objs.size();
     F.world_in_lds = big ? 0 : 1;
-    sd.lds_bytes = big ? (size_t)PT_BVH_STACK * PT_BLOCK * sizeof(int)
+    // LDS plan of the BVH path: per-lane stacks sized by the tree depth, and the first (top-level)
+    // nodes of the main tree in what is left of a 40 KiB budget (4 blocks of 256 threads per CU)
+    F.bvh_stack = big ? std::max(8, ((sd.bvh_depth + 1 + 3) / 4) * 4) : 0;
+    const size_t stack_bytes = (size_t)F.bvh_stack * PT_BLOCK * sizeof(int);
+    F.bvh_lds_nodes = 0;
+    if (big && F.bvh_root == 0 && stack_bytes < 40960)
+        F.bvh_lds_nodes = (int32_t)std::min<size_t>((40960 - stack_bytes) / sizeof(BvhNode), (size_t)F.bvh_main_nodes);
+    sd.lds_bytes = big ? stack_bytes + (size_t)F.bvh_lds_nodes * sizeof(BvhNode)
                        : (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
                              (size_t)(sd.bsph.size() + sd.bbox.size()) * sizeof(int);
     if (sd.lds_bytes > 160 * 1024)
