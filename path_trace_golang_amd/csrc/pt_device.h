@@ -129,6 +129,7 @@ struct DevFrame {
     float origin_bound;  // rays whose origin leaves [-origin_bound, origin_bound]^3 keep every candidate
     float pad_f;
     double scene_bound;  // Bs: every finite object (inflated) lies inside [-Bs, Bs]^3
+    double margin;       // m = B/4096: inflation of every FP32 bound
     uint64_t seed_key;   // ptm::seed_key(seed)
     double inv_width;    // 1/(W-1)  renderer.go:95
     double inv_height;   // 1/(H-1)  renderer.go:96

@@ -222,6 +222,41 @@ __device__ __forceinline__ void scan_uniform(const DevFrame &F, ObjPtr g_obj, co
     }
 }
 
+
+// A ray against the cube [-Bs, Bs]^3 that holds every finite object, in FP64.
+//   inside   : the origin is in the cube (ts = 0, nothing else to do)
+//   miss     : the ray never is inside the cube at a parameter >= tmin  -> no sphere or box can be hit
+//   te, ts   : entry parameter; the FP32 tests run from the entry point o + d*ts (parameters relative to ts)
+//   far      : the origin is so far out (more than ~2000 scene sizes) that the REFERENCE's own FP64 tests
+//              lose their meaning there: halfB*halfB - a*c cancels catastrophically and "hits" appear
+//              well outside the geometry.  Culling by geometry would drop those bit-exact artefacts, so
+//              such rays take the plain every-object scan.
+// v_min/v_max skip the NaN of a 0 * inf slab boundary, which leaves that slab unconstrained: conservative.
+struct Clip {
+    double ts, te;
+    bool miss, far;
+};
+__device__ __forceinline__ Clip clip_ray(const DevFrame &F, const RayD &r, double tmin) {
+    Clip c{0.0, 0.0, false, false};
+    const double Bs = F.scene_bound;
+    if (!(ptm::f_abs(r.ox) <= Bs && ptm::f_abs(r.oy) <= Bs && ptm::f_abs(r.oz) <= Bs)) {
+        const double ix = 1 / r.dx, iy = 1 / r.dy, iz = 1 / r.dz;
+        const double x0 = (-Bs - r.ox) * ix, x1 = (Bs - r.ox) * ix;
+        const double y0 = (-Bs - r.oy) * iy, y1 = (Bs - r.oy) * iy;
+        const double z0 = (-Bs - r.oz) * iz, z1 = (Bs - r.oz) * iz;
+        const double te = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmin(z0, z1));
+        const double tx = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmax(z0, z1));
+        c.miss = te > tx || tx < tmin;
+        c.te = te;
+        c.ts = (te > 0 && !c.miss) ? te : 0;
+        const double reach = ptm::f_abs(r.ox) + ptm::f_abs(r.oy) + ptm::f_abs(r.oz) +
+                             (ptm::f_abs(r.dx) + ptm::f_abs(r.dy) + ptm::f_abs(r.dz)) * ptm::f_abs(te);
+        // error of the reference's sphere discriminant in distance^2: ~2^-50 reach^2; it must stay far inside m^2
+        c.far = !(reach * 3.0e-8 <= F.margin * 0.25);
+    }
+    return c;
+}
+
 // Order-free statement of the sequential winner.  Closest-hit mode: smallest t; on an exact tie a
 // sphere/plane beats a box (their range test is inclusive, objects.go:56-60, :110, the box's is
 // exclusive, :176), among spheres/planes the higher index wins, among boxes the lower.  Exit mode:
@@ -238,8 +273,8 @@ __device__ __forceinline__ bool wins(int mode, bool is_box, int i, double t, int
 // Broad phase in FP32 over inflated bounds + exact FP64 narrow phase over the survivors.
 template <bool PROF, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
 __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_obj, SphPtr g_bs, BoxPtr g_bb, IdxPtr g_pl,
-                                                  const DevObj *s_obj, const int *s_kidx, const RayD &r, int mode, int &best,
-                                                  double &tmax, const ProfHooks &ph) {
+                                                  const DevObj *s_obj, const int *s_kidx, const RayD &r, const Clip &clip,
+                                                  int mode, int &best, double &tmax, const ProfHooks &ph) {
     const double tmin = mode ? 0.0001 : 0.001;
     tmax = ptm::max_float64();
     best = -1;
@@ -266,26 +301,9 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     PH_END(SEC_PLANE)
     // ---- broad phase
     PH_BEGIN(SEC_BROAD)
-    // Rays that start far outside the scene (bounces off the infinite ground plane) are clipped in FP64
-    // against the cube [-Bs, Bs]^3 holding every finite object: a miss means no sphere or box can be hit,
-    // otherwise the FP32 tests run from the entry point (parameters relative to ts), inside the range the
-    // margin analysis covers.  v_min/v_max skip the NaN of a 0 * inf slab boundary: conservative.
-    double ts = 0;
-    bool outside_all = false;
-    {
-        const double Bs = F.scene_bound;
-        if (!(ptm::f_abs(r.ox) <= Bs && ptm::f_abs(r.oy) <= Bs && ptm::f_abs(r.oz) <= Bs)) {
-            const double ix = 1 / r.dx, iy = 1 / r.dy, iz = 1 / r.dz;
-            const double x0 = (-Bs - r.ox) * ix, x1 = (Bs - r.ox) * ix;
-            const double y0 = (-Bs - r.oy) * iy, y1 = (Bs - r.oy) * iy;
-            const double z0 = (-Bs - r.oz) * iz, z1 = (Bs - r.oz) * iz;
-            const double te = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmin(z0, z1));
-            const double tx = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmax(z0, z1));
-            outside_all = te > tx || tx < tmin || te > tmax;
-            ts = te > 0 ? te : 0;
-            if (outside_all) ts = 0;
-        }
-    }
+    // rays from outside the scene cube start their FP32 tests at the entry point (clip_ray)
+    const double ts = clip.ts;
+    const bool outside_all = clip.miss || clip.te > tmax;
     const float fox = (float)(r.ox + r.dx * ts), foy = (float)(r.oy + r.dy * ts), foz = (float)(r.oz + r.dz * ts);
     const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
     const float fa = __builtin_fmaf(fdx, fdx, __builtin_fmaf(fdy, fdy, fdz * fdz));
@@ -377,7 +395,7 @@ template <bool PROF, typename ObjPtr, typename IdxPtr>
 __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr g_pl, const BvhNode *__restrict__ nodes,
                                          const BvhNode *lds_nodes /* nodes[0 .. F.bvh_lds_nodes) staged in LDS */,
                                          const BvhObj *__restrict__ bobjs, int *stack /* this lane's column, stride PT_BLOCK */,
-                                         const RayD &r, int mode, int &best, double &tmax, const ProfHooks &ph) {
+                                         const RayD &r, const Clip &clip, int mode, int &best, double &tmax, const ProfHooks &ph) {
     const double tmin = mode ? 0.0001 : 0.001;
     tmax = ptm::max_float64();
     best = -1;
@@ -404,22 +422,10 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     if (root < 0) return;
 
     const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
-    // Rays that start far outside the scene (a bounce off the infinite ground plane hundreds of units
-    // away) would lose the FP32 margin analysis, which assumes |origin| <= 4B.  Clip them in FP64 against
-    // the cube [-Bs, Bs]^3 that holds every finite object: a ray that misses the cube cannot hit any of
-    // them, the others are re-based to their entry point (ts) for the FP32 node tests.  v_min/v_max skip
-    // NaNs (0 * inf on a slab boundary), which leaves that slab unconstrained: conservative.
-    double ts = 0;
-    const double Bs = F.scene_bound;
-    if (!(ptm::f_abs(r.ox) <= Bs && ptm::f_abs(r.oy) <= Bs && ptm::f_abs(r.oz) <= Bs)) {
-        const double x0 = (-Bs - r.ox) * ivx, x1 = (Bs - r.ox) * ivx;
-        const double y0 = (-Bs - r.oy) * ivy, y1 = (Bs - r.oy) * ivy;
-        const double z0 = (-Bs - r.oz) * ivz, z1 = (Bs - r.oz) * ivz;
-        const double te = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmin(z0, z1));
-        const double tx = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmax(z0, z1));
-        if (te > tx || tx < tmin || te > tmax) return;  // never inside the cube at a useful parameter
-        ts = te > 0 ? te : 0;
-    }
+    // rays from outside the scene cube: a miss ends the scan, the others start their FP32 node tests at the
+    // entry point (clip_ray); parameters below are relative to ts
+    if (clip.miss || clip.te > tmax) return;
+    const double ts = clip.ts;
     const float fox = (float)(r.ox + r.dx * ts), foy = (float)(r.oy + r.dy * ts), foz = (float)(r.oz + r.dz * ts);
     const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
     const float fa = __builtin_fmaf(fdx, fdx, __builtin_fmaf(fdy, fdy, fdz * fdz));
@@ -779,32 +785,32 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             double tmax;
             if (SCAN == SCAN_UNIFORM) {
                 scan_uniform(F, g_obj, ray, mode, best, tmax);
-            } else if (SCAN == SCAN_BROAD) {
-                // The order-free winner rule assumes every candidate t is a number.  Rays with
-                // non-finite or absurd components (e.g. a 1-pixel-wide frame divides by W-1 = 0,
-                // renderer.go:95) can produce NaN roots, and those follow the sequential loop's
-                // NaN behaviour only in the sequential loop: such waves take the plain scan.
+            } else {
+                // The culled strategies assume every candidate t is a number and that the reference's FP64 tests
+                // mean what the geometry says.  Rays with non-finite or absurd components (a 1-pixel-wide frame
+                // divides by W-1 = 0, renderer.go:95) and rays from astronomically far away (clip_ray) break
+                // that: a wave holding one takes the plain sequential scan, which IS the reference's loop.
                 const double a_ = dx * dx + dy * dy + dz * dz;
+                const Clip clip = clip_ray(F, ray, mode ? 0.0001 : 0.001);
                 const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
-                                  (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100);
-                if (__ballot(!tame) != 0) scan_uniform(F, g_obj, ray, mode, best, tmax);
-                else scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, mode, best, tmax, ph);
-            } else if (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) {
-                const double a_ = dx * dx + dy * dy + dz * dz;
-                const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
-                                  (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100);
-                if (__ballot(!tame) != 0) {
+                                  (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100) && !clip.far;
+                const bool plain = __ballot(!tame) != 0;
+                constexpr bool VERIFY = (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_BVH);
+                if (plain) {
                     scan_uniform(F, g_obj, ray, mode, best, tmax);
                 } else {
-                    scan_bvh<PROF>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, mode, best, tmax, ph);
-                    if (SCAN == SCAN_VERIFY_BVH) {
+                    if (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY)
+                        scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
+                    else
+                        scan_bvh<PROF>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, clip, mode,
+                                       best, tmax, ph);
+                    if (VERIFY) {
                         int best2;
                         double tmax2;
                         scan_uniform(F, g_obj, ray, mode, best2, tmax2);
                         if (best != best2 || (best >= 0 && !(tmax == tmax2))) {
                             c_mismatch++;
-                            // diagnostics: one disagreeing segment (racy, any one will do)
-                            unsigned long long *dbg = B.counters + 8;
+                            unsigned long long *dbg = B.counters + 8;  // one disagreeing segment (racy, any one will do)
                             dbg[0] = ((unsigned long long)(uint32_t)best << 32) | (uint32_t)best2;
                             dbg[1] = ptm::to_bits(tmax);
                             dbg[2] = ptm::to_bits(tmax2);
@@ -816,15 +822,6 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                         tmax = tmax2;
                     }
                 }
-            } else {
-                int best2;
-                double tmax2;
-                scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, mode, best2, tmax2, ph);
-                scan_uniform(F, g_obj, ray, mode, best, tmax);
-                const double a_ = dx * dx + dy * dy + dz * dz;
-                const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
-                                  (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100);
-                if (tame && (best != best2 || (best >= 0 && !(tmax == tmax2)))) c_mismatch++;
             }
             SEC_END(SEC_SCAN)
             // -------------------------------------------------------- shade

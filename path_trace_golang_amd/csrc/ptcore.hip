@@ -382,6 +382,7 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     F.box_all = fr.bbox.size() >= 32 ? 0xffffffffu : ((1u << fr.bbox.size()) - 1u);
     F.origin_bound = (float)std::min(4.0 * B, 3.0e38);
     F.scene_bound = B * (1.0 + 1.0 / 512.0);  // the inflation is B/4096
+    F.margin = m;
 }
 
 int32_t tiles_of_shard(int32_t ntiles, const pt_shard &sh) {
