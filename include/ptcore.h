@@ -225,6 +225,29 @@ int32_t pt_untile_device(pt_ctx *ctx, int32_t width, int32_t height, int32_t sha
                          void *d_accum, void *stream);
 
 /*
+ * Optional post-process passes of the reference's OpenGL backend, applied after a render:
+ *   tonemap : rgba = uint8(sqrt(aces(float32(accum/spp)))*255 + 0.5)   acesTonemap internal/engine/gpu/gpu.go:22-47,
+ *             the loop at gpu.go:2309-2350 -- replaces the CPU engine's finish; needs `accum`
+ *   denoise : 3x3 bilateral filter on the 8-bit image, gpu.go:2355-2439 (defaults sigma_s 1.0, sigma_r 0.15,
+ *             gpu.go:77-95; skipped unless width > 2 && height > 2)
+ *   smooth  : box blur of radius 1..5 blended by strength 0..1, gpu.go:2444-2520 (defaults 2 and 0.5, gpu.go:140-175)
+ * None of them is part of the CPU engine's image; they exist so that a user of the reference's -gpu look can have
+ * it.  rgba is `height` rows of `stride` bytes in host memory, updated in place; accum (width*height*3 doubles, the
+ * raw sums pt_render returns) may be NULL when tonemap is 0.
+ */
+typedef struct pt_post_config {
+    int32_t tonemap;
+    int32_t denoise;
+    double sigma_s;
+    double sigma_r;
+    int32_t smooth;
+    int32_t smooth_radius;
+    double smooth_strength;
+} pt_post_config;
+int32_t pt_post_process(pt_ctx *ctx, const pt_post_config *post, const double *accum, int32_t samples_per_px, uint8_t *rgba,
+                        int32_t stride, int32_t width, int32_t height);
+
+/*
  * Diagnostics only (not part of the rendering boundary): with PTCORE_PROFILE=1 in the
  * environment at pt_create, the trace kernel runs a build that counts, per code
  * section, wave executions, active lanes and shader-clock cycles.  Copies up to n

@@ -51,6 +51,11 @@ class OraConfig(C.Structure):
                 ("seed", C.c_uint64), ("workers", C.c_int32), ("_pad", C.c_int32)]
 
 
+class OraPostConfig(C.Structure):
+    _fields_ = [("tonemap", C.c_int32), ("denoise", C.c_int32), ("sigma_s", C.c_double), ("sigma_r", C.c_double),
+                ("smooth", C.c_int32), ("smooth_radius", C.c_int32), ("smooth_strength", C.c_double)]
+
+
 class OraStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("exit_scans", C.c_uint64),
                 ("draws", C.c_uint64), ("seconds", C.c_double), ("workers", C.c_int32), ("_pad", C.c_int32)]
@@ -103,6 +108,11 @@ def lib():
         L.ora_convert_material.argtypes = [C.POINTER(OraMaterial), dp]
         L.ora_camera_setup.restype = None
         L.ora_camera_setup.argtypes = [C.POINTER(OraCamera), C.c_int32, C.c_int32, dp]
+        L.ora_post_process.restype = None
+        L.ora_post_process.argtypes = [C.POINTER(OraPostConfig), C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_int32]
+        L.ora_aces_tonemap.restype = C.c_float
+        L.ora_aces_tonemap.argtypes = [C.c_float]
         L.ora_finish_pixel.restype = None
         L.ora_finish_pixel.argtypes = [dp, C.c_int32, C.POINTER(C.c_uint8)]
         _lib = L
@@ -239,3 +249,13 @@ def hit(kind: int, a, b, radius, orig, dir_, tmin, tmax):
     ok = L.ora_hit(kind, d3(*a), d3(*b), radius, d3(*orig), d3(*dir_), tmin, tmax, out)
     return bool(ok), {"t": out[0], "p": [out[1], out[2], out[3]], "n": [out[4], out[5], out[6]],
                       "front": bool(out[7])}
+
+
+def post_process(img, tonemap=False, denoise=False, sigma_s=1.0, sigma_r=0.15, smooth=False, smooth_radius=2,
+                 smooth_strength=0.5, accum=None, spp=1):
+    """In-place CPU restatement of the reference GPU backend's post passes on img (uint8 [H, W, 4])."""
+    L = lib()
+    cfg = OraPostConfig(int(tonemap), int(denoise), sigma_s, sigma_r, int(smooth), smooth_radius, smooth_strength)
+    h, w = img.shape[0], img.shape[1]
+    L.ora_post_process(C.byref(cfg), accum.ctypes.data_as(C.c_void_p) if accum is not None else None, spp,
+                       img.ctypes.data_as(C.c_void_p), int(img.strides[0]), w, h)

@@ -989,3 +989,134 @@ void ora_camera_setup(const ora_camera *c, int32_t width, int32_t height, double
     for (int i = 0; i < 7; i++) { out[3 * i] = vs[i]->x; out[3 * i + 1] = vs[i]->y; out[3 * i + 2] = vs[i]->z; }
     out[21] = cam.lensRadius;
 }
+
+/* ------------------------------------------------------------------ */
+/* post-process passes of the reference GPU backend (N4)               */
+/* ------------------------------------------------------------------ */
+
+/* gpu.go:22-47 */
+float ora_aces_tonemap(float x) {
+    if (x <= 0) return 0;
+    const double a = 2.51, b = 0.03, c = 2.43, d = 0.59, e = 0.14;
+    double y = (double)x;
+    double num = y * (a * y + b);
+    double den = y * (c * y + d) + e;
+    if (den <= 0) return 0;
+    double r = num / den;
+    if (r < 0) r = 0;
+    else if (r > 1) r = 1;
+    return (float)r;
+}
+
+static uint8_t to_u8_f32(float g) { /* uint8(g*255.0 + 0.5) in float32 arithmetic, gpu.go:2346-2348 */
+    float v = g * 255.0f;
+    v = v + 0.5f;
+    return (uint8_t)v;
+}
+
+void ora_post_process(const ora_post_config *cfg, const double *accum, int32_t spp, uint8_t *rgba, int32_t stride,
+                      int32_t w, int32_t h) {
+    if (cfg->tonemap && accum) { /* gpu.go:2309-2350 */
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                uint8_t *px = rgba + (size_t)y * (size_t)stride + (size_t)x * 4;
+                for (int c = 0; c < 3; c++) {
+                    float lin = (float)(accum[((size_t)y * (size_t)w + (size_t)x) * 3 + c] / (double)spp);
+                    if (lin < 0) lin = 0;
+                    float tm = ora_aces_tonemap(lin);
+                    float g = (float)sqrt((double)tm);
+                    if (g > 1) g = 1;
+                    px[c] = to_u8_f32(g);
+                }
+                px[3] = 255;
+            }
+    }
+    size_t bytes = (size_t)stride * (size_t)h;
+    if (cfg->denoise && w > 2 && h > 2) { /* gpu.go:2355-2439 */
+        uint8_t *sm = (uint8_t *)malloc(bytes);
+        memcpy(sm, rgba, bytes);
+        double twoSigmaS2 = 2 * cfg->sigma_s * cfg->sigma_s;
+        double twoSigmaR2 = 2 * cfg->sigma_r * cfg->sigma_r;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const uint8_t *cp = rgba + (size_t)y * (size_t)stride + (size_t)x * 4;
+                double cr = (double)cp[0] / 255.0, cg = (double)cp[1] / 255.0, cb = (double)cp[2] / 255.0;
+                double sumR = 0, sumG = 0, sumB = 0, sumW = 0;
+                for (int ky = -1; ky <= 1; ky++) {
+                    int ny = y + ky;
+                    if (ny < 0 || ny >= h) continue;
+                    for (int kx = -1; kx <= 1; kx++) {
+                        int nx = x + kx;
+                        if (nx < 0 || nx >= w) continue;
+                        const uint8_t *np = rgba + (size_t)ny * (size_t)stride + (size_t)nx * 4;
+                        double nr = (double)np[0] / 255.0, ng = (double)np[1] / 255.0, nb = (double)np[2] / 255.0;
+                        double ds2 = (double)(kx * kx + ky * ky);
+                        double dr = cr - nr, dg = cg - ng, dbb = cb - nb;
+                        double dr2 = dr * dr + dg * dg + dbb * dbb;
+                        double ws = ora_exp(-ds2 / twoSigmaS2);
+                        double wr = ora_exp(-dr2 / twoSigmaR2);
+                        double wgt = ws * wr;
+                        sumW += wgt;
+                        sumR += nr * wgt;
+                        sumG += ng * wgt;
+                        sumB += nb * wgt;
+                    }
+                }
+                uint8_t *op = sm + (size_t)y * (size_t)stride + (size_t)x * 4;
+                if (sumW > 0) {
+                    double v[3] = {sumR / sumW, sumG / sumW, sumB / sumW};
+                    for (int c = 0; c < 3; c++) {
+                        if (v[c] < 0) v[c] = 0;
+                        else if (v[c] > 1) v[c] = 1;
+                        op[c] = (uint8_t)(v[c] * 255.0 + 0.5);
+                    }
+                    op[3] = 255;
+                } else {
+                    memcpy(op, cp, 4);
+                }
+            }
+        memcpy(rgba, sm, bytes);
+        free(sm);
+    }
+    if (cfg->smooth && w > 2 && h > 2 && cfg->smooth_radius > 0 && cfg->smooth_strength > 0) { /* gpu.go:2444-2520 */
+        int rad = cfg->smooth_radius;
+        if (rad < 1) rad = 1;
+        if (rad > 5) rad = 5;
+        double str = cfg->smooth_strength;
+        if (str < 0) str = 0;
+        if (str > 1) str = 1;
+        uint8_t *bl = (uint8_t *)calloc(bytes, 1); /* make([]byte, len(dst)): zero-filled, padding bytes included */
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                double sumR = 0, sumG = 0, sumB = 0, count = 0;
+                for (int ky = -rad; ky <= rad; ky++) {
+                    int ny = y + ky;
+                    if (ny < 0 || ny >= h) continue;
+                    for (int kx = -rad; kx <= rad; kx++) {
+                        int nx = x + kx;
+                        if (nx < 0 || nx >= w) continue;
+                        const uint8_t *np = rgba + (size_t)ny * (size_t)stride + (size_t)nx * 4;
+                        sumR += (double)np[0];
+                        sumG += (double)np[1];
+                        sumB += (double)np[2];
+                        count++;
+                    }
+                }
+                if (count > 0) {
+                    const uint8_t *cp = rgba + (size_t)y * (size_t)stride + (size_t)x * 4;
+                    uint8_t *op = bl + (size_t)y * (size_t)stride + (size_t)x * 4;
+                    double avg[3] = {sumR / count, sumG / count, sumB / count};
+                    for (int c = 0; c < 3; c++) {
+                        double out = (1 - str) * (double)cp[c] + str * avg[c];
+                        if (out < 0) out = 0;
+                        else if (out > 255) out = 255;
+                        op[c] = (uint8_t)(out + 0.5);
+                    }
+                    op[3] = 255;
+                }
+            }
+        /* copy(dst, blurred): the reference image has Stride == 4*w, so only pixel bytes exist */
+        for (int y = 0; y < h; y++) memcpy(rgba + (size_t)y * (size_t)stride, bl + (size_t)y * (size_t)stride, (size_t)w * 4);
+        free(bl);
+    }
+}

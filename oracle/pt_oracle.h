@@ -125,6 +125,21 @@ int ora_hit(int32_t kind, const double a[3], const double b[3], double radius, c
 void ora_convert_material(const ora_material *m, double out[12]);
 /* camera: out = origin[3], lowerLeft[3], horizontal[3], vertical[3], u[3], v[3], w[3], lensRadius (22) */
 void ora_camera_setup(const ora_camera *c, int32_t width, int32_t height, double out[22]);
+/* ---- post-process passes of the reference's GPU backend, CPU restatement ----
+ * internal/engine/gpu/gpu.go:22-47 (acesTonemap), :2309-2350 (tone-map + gamma + round), :2355-2439
+ * (3x3 bilateral on the 8-bit image), :2444-2520 (box blur blended with the original). */
+typedef struct {
+    int32_t tonemap;        /* 1: rgba = round(sqrt(aces(float32(accum/spp))) * 255), needs accum */
+    int32_t denoise;        /* 1: bilateral 3x3, skipped unless w > 2 && h > 2 (gpu.go:2358) */
+    double sigma_s, sigma_r;
+    int32_t smooth;         /* 1: box blur, radius clamped to 1..5, strength to 0..1 */
+    int32_t smooth_radius;
+    double smooth_strength;
+} ora_post_config;
+void ora_post_process(const ora_post_config *cfg, const double *accum, int32_t spp, uint8_t *rgba, int32_t stride,
+                      int32_t width, int32_t height);
+float ora_aces_tonemap(float x);
+
 /* pixel finish (renderer.go:190-221): raw sum -> 3 bytes */
 void ora_finish_pixel(const double sum[3], int32_t spp, uint8_t out[3]);
 

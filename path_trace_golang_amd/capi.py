@@ -57,6 +57,11 @@ class PtConfig(C.Structure):
                 ("max_depth", C.c_int32), ("seed", C.c_uint64), ("spp_chunk", C.c_int32), ("flags", C.c_int32)]
 
 
+class PtPostConfig(C.Structure):
+    _fields_ = [("tonemap", C.c_int32), ("denoise", C.c_int32), ("sigma_s", C.c_double), ("sigma_r", C.c_double),
+                ("smooth", C.c_int32), ("smooth_radius", C.c_int32), ("smooth_strength", C.c_double)]
+
+
 class PtShard(C.Structure):
     _fields_ = [("index", C.c_int32), ("count", C.c_int32)]
 
@@ -94,6 +99,7 @@ SYMBOLS = [
                                             _vp, C.POINTER(PtStats)]),
     ("pt_untile_device", C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp,
                                       _vp]),
+    ("pt_post_process", C.c_int32, [_vp, C.POINTER(PtPostConfig), _vp, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32]),
     ("pt_debug_profile", C.c_int32, [_vp, C.POINTER(C.c_uint64), C.c_int32]),
     ("pt_debug_scan_mismatches", C.c_int64, [_vp]),
     ("pt_debug_bvh_check", C.c_int32, [C.POINTER(PtScene), C.POINTER(C.c_int32)]),

@@ -1211,4 +1211,122 @@ __global__ __launch_bounds__(PT_BLOCK) void untile_kernel(const UntileArgs U) {
     if (U.u32b) U.u32b[o] = U.tiles_u32b[pix];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Optional post-process passes of the reference's GPU backend.  They are NOT part of
+// the CPU engine's look and are off unless asked for.  All three are per-pixel, bandwidth-bound passes
+// over a tightly packed RGBA8 frame (row stride 4*width).
+
+// acesTonemap, gpu.go:22-47
+__device__ __forceinline__ float aces_tonemap(float x) {
+    if (x <= 0) return 0;
+    const double y = (double)x;
+    const double num = y * (2.51 * y + 0.03);
+    const double den = y * (2.43 * y + 0.59) + 0.14;
+    if (den <= 0) return 0;
+    double r = num / den;
+    if (r < 0) r = 0;
+    else if (r > 1) r = 1;
+    return (float)r;
+}
+
+// gpu.go:2309-2350: clamp, ACES, sqrt gamma, uint8(g*255.0 + 0.5) in float32 arithmetic
+__global__ __launch_bounds__(PT_BLOCK) void post_tonemap_kernel(const double *__restrict__ accum, double inv_spp_is_unused,
+                                                                  int32_t spp, uint8_t *__restrict__ rgba, int32_t npix) {
+    (void)inv_spp_is_unused;
+    const int32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= npix) return;
+    uint32_t packed = 255u << 24;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float lin = (float)(accum[(size_t)i * 3 + c] / (double)spp);
+        if (lin < 0) lin = 0;
+        const float tm = aces_tonemap(lin);
+        float g = (float)ptm::f_sqrt((double)tm);
+        if (g > 1) g = 1;
+        float v = g * 255.0f;
+        v = v + 0.5f;
+        packed |= ((uint32_t)v & 0xffu) << (8 * c);
+    }
+    reinterpret_cast<uint32_t *>(rgba)[i] = packed;
+}
+
+// gpu.go:2355-2439: 3x3 bilateral filter on the 8-bit image (spatial sigma_s, range sigma_r in sRGB 0..1)
+__global__ __launch_bounds__(PT_BLOCK) void post_bilateral_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int32_t w,
+                                                                    int32_t h, double two_sigma_s2, double two_sigma_r2) {
+    const int32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= w * h) return;
+    const int32_t x = i % w, y = i / w;
+    const uint32_t cpk = reinterpret_cast<const uint32_t *>(src)[i];
+    const double cr = (double)(cpk & 0xffu) / 255.0, cg = (double)((cpk >> 8) & 0xffu) / 255.0,
+                 cb = (double)((cpk >> 16) & 0xffu) / 255.0;
+    double sumR = 0, sumG = 0, sumB = 0, sumW = 0;
+    for (int ky = -1; ky <= 1; ky++) {
+        const int ny = y + ky;
+        if (ny < 0 || ny >= h) continue;
+        for (int kx = -1; kx <= 1; kx++) {
+            const int nx = x + kx;
+            if (nx < 0 || nx >= w) continue;
+            const uint32_t npk = reinterpret_cast<const uint32_t *>(src)[(size_t)ny * w + nx];
+            const double nr = (double)(npk & 0xffu) / 255.0, ng = (double)((npk >> 8) & 0xffu) / 255.0,
+                         nb = (double)((npk >> 16) & 0xffu) / 255.0;
+            const double ds2 = (double)(kx * kx + ky * ky);
+            const double dr = cr - nr, dg = cg - ng, dbb = cb - nb;
+            const double dr2 = dr * dr + dg * dg + dbb * dbb;
+            const double ws = ptm::go_exp(-ds2 / two_sigma_s2);
+            const double wr = ptm::go_exp(-dr2 / two_sigma_r2);
+            const double wgt = ws * wr;
+            sumW += wgt;
+            sumR += nr * wgt;
+            sumG += ng * wgt;
+            sumB += nb * wgt;
+        }
+    }
+    uint32_t out = cpk;
+    if (sumW > 0) {
+        double v[3] = {sumR / sumW, sumG / sumW, sumB / sumW};
+        out = 255u << 24;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double q = v[c];
+            if (q < 0) q = 0;
+            else if (q > 1) q = 1;
+            out |= ((uint32_t)(q * 255.0 + 0.5) & 0xffu) << (8 * c);
+        }
+    }
+    reinterpret_cast<uint32_t *>(dst)[i] = out;
+}
+
+// gpu.go:2444-2520: box average of radius 1..5 blended with the original by `strength`
+__global__ __launch_bounds__(PT_BLOCK) void post_smooth_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int32_t w,
+                                                                 int32_t h, int32_t rad, double str) {
+    const int32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (i >= w * h) return;
+    const int32_t x = i % w, y = i / w;
+    double sumR = 0, sumG = 0, sumB = 0, count = 0;
+    for (int ky = -rad; ky <= rad; ky++) {
+        const int ny = y + ky;
+        if (ny < 0 || ny >= h) continue;
+        for (int kx = -rad; kx <= rad; kx++) {
+            const int nx = x + kx;
+            if (nx < 0 || nx >= w) continue;
+            const uint32_t npk = reinterpret_cast<const uint32_t *>(src)[(size_t)ny * w + nx];
+            sumR += (double)(npk & 0xffu);
+            sumG += (double)((npk >> 8) & 0xffu);
+            sumB += (double)((npk >> 16) & 0xffu);
+            count++;
+        }
+    }
+    const uint32_t cpk = reinterpret_cast<const uint32_t *>(src)[i];
+    const double avg[3] = {sumR / count, sumG / count, sumB / count};
+    uint32_t out = 255u << 24;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double o = (1 - str) * (double)((cpk >> (8 * c)) & 0xffu) + str * avg[c];
+        if (o < 0) o = 0;
+        else if (o > 255) o = 255;
+        out |= ((uint32_t)(o + 0.5) & 0xffu) << (8 * c);
+    }
+    reinterpret_cast<uint32_t *>(dst)[i] = out;
+}
+
 }  // namespace ptk

@@ -920,6 +920,48 @@ void pt_destroy(pt_ctx *ctx) {
     delete ctx;
 }
 
+int32_t pt_post_process(pt_ctx *ctx, const pt_post_config *post, const double *accum, int32_t spp, uint8_t *rgba, int32_t stride,
+                        int32_t width, int32_t height) {
+    if (!ctx || !post || !rgba) return fail(PT_ERR_INVALID, "null argument");
+    if (width <= 0 || height <= 0 || stride < width * 4) return fail(PT_ERR_INVALID, "bad frame size or stride");
+    if (post->tonemap && !accum) return fail(PT_ERR_INVALID, "tonemap needs the accum buffer");
+    if (ctx->frame.open) return fail(PT_ERR_STATE, "a frame is open");
+    Device &d = ctx->devs[0];
+    HIP_TRY(hipSetDevice(d.ordinal));
+    const size_t npix = (size_t)width * (size_t)height;
+    HIP_TRY(ctx->f_rgba.reserve(npix * 4));
+    HIP_TRY(ctx->g_tiles_rgba.reserve(npix * 4));  // second frame-sized byte buffer (ping-pong)
+    uint8_t *cur = ctx->f_rgba.p, *other = ctx->g_tiles_rgba.p;
+    hipStream_t s = d.own_stream;
+    const unsigned grid = (unsigned)((npix + PT_BLOCK - 1) / PT_BLOCK);
+    if (post->tonemap) {
+        HIP_TRY(ctx->f_accum.reserve(npix * 3));
+        HIP_TRY(hipMemcpyAsync(ctx->f_accum.p, accum, npix * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(ptk::post_tonemap_kernel, dim3(grid), dim3(PT_BLOCK), 0, s, ctx->f_accum.p, 0.0, spp, cur, (int32_t)npix);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(cur, (size_t)width * 4, rgba, (size_t)stride, (size_t)width * 4, (size_t)height,
+                                 hipMemcpyHostToDevice, s));
+    }
+    if (post->denoise && width > 2 && height > 2) {
+        const double ss = post->sigma_s > 0 ? post->sigma_s : 1.0, sr = post->sigma_r > 0 ? post->sigma_r : 0.15;
+        hipLaunchKernelGGL(ptk::post_bilateral_kernel, dim3(grid), dim3(PT_BLOCK), 0, s, cur, other, width, height, 2 * ss * ss,
+                           2 * sr * sr);
+        HIP_TRY(hipGetLastError());
+        std::swap(cur, other);
+    }
+    if (post->smooth && width > 2 && height > 2 && post->smooth_radius > 0 && post->smooth_strength > 0) {
+        const int32_t rad = std::max(1, std::min(5, post->smooth_radius));
+        const double str = std::max(0.0, std::min(1.0, post->smooth_strength));
+        hipLaunchKernelGGL(ptk::post_smooth_kernel, dim3(grid), dim3(PT_BLOCK), 0, s, cur, other, width, height, rad, str);
+        HIP_TRY(hipGetLastError());
+        std::swap(cur, other);
+    }
+    HIP_TRY(hipMemcpy2DAsync(rgba, (size_t)stride, cur, (size_t)width * 4, (size_t)width * 4, (size_t)height, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PT_OK;
+}
+
 int32_t pt_debug_profile(pt_ctx *ctx, uint64_t *out, int32_t n) {
     if (!ctx || !out) return fail(PT_ERR_INVALID, "null argument");
     if (!ctx->profile_sections) return fail(PT_ERR_STATE, "set PTCORE_PROFILE=1 before pt_create");

@@ -167,3 +167,62 @@ def render(sc: scn.Scene, cfg: RenderConfig, img: np.ndarray, progress: Optional
     capi.check(rc)
     progress()
     return st.as_dict()
+
+
+@dataclass
+class PostConfig:
+    """Post-process passes of the reference's OpenGL backend (gpu.go:22-47, :2309-2520); all off by default
+    because they are not part of the CPU engine's image."""
+    tonemap: bool = False
+    denoise: bool = False
+    sigma_s: float = 1.0
+    sigma_r: float = 0.15
+    smooth: bool = False
+    smooth_radius: int = 2
+    smooth_strength: float = 0.5
+
+    @classmethod
+    def from_env(cls, environ=None) -> "PostConfig":
+        """The reference's switches: PATHTRACER_GPU_DENOISE (default on there), _SIGMA_S, _SIGMA_R (gpu.go:77-95),
+        PATHTRACER_GPU_SMOOTH (default off), _RADIUS, _STRENGTH (gpu.go:140-175); tone mapping always on."""
+        import os
+
+        env = os.environ if environ is None else environ
+        cfg = cls(tonemap=True, denoise=True)
+        v = env.get("PATHTRACER_GPU_DENOISE", "").lower()
+        if v in ("0", "false", "off", "no"):
+            cfg.denoise = False
+        for key, attr in (("PATHTRACER_GPU_DENOISE_SIGMA_S", "sigma_s"), ("PATHTRACER_GPU_DENOISE_SIGMA_R", "sigma_r")):
+            try:
+                f = float(env[key])
+                if f > 0:
+                    setattr(cfg, attr, f)
+            except (KeyError, ValueError):
+                pass
+        v = env.get("PATHTRACER_GPU_SMOOTH", "").lower()
+        if v in ("1", "true", "on", "yes"):
+            cfg.smooth = True
+        try:
+            cfg.smooth_radius = max(1, min(5, int(env["PATHTRACER_GPU_SMOOTH_RADIUS"])))
+        except (KeyError, ValueError):
+            pass
+        try:
+            cfg.smooth_strength = max(0.0, min(1.0, float(env["PATHTRACER_GPU_SMOOTH_STRENGTH"])))
+        except (KeyError, ValueError):
+            pass
+        return cfg
+
+
+def post_process(img: np.ndarray, post: PostConfig, accum: Optional[np.ndarray] = None, samples_per_px: int = 1,
+                 ctx: Optional[capi.Context] = None) -> None:
+    """Applies the selected passes to img (uint8 [H, W, 4]) in place on the GPU."""
+    L = capi.load()
+    ctx = ctx or context()
+    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 4 or img.strides[2] != 1 or img.strides[1] != 4:
+        raise ValueError("img must be uint8 [H, W, 4] with contiguous RGBA rows")
+    h, w = img.shape[0], img.shape[1]
+    if accum is not None and (accum.dtype != np.float64 or accum.shape != (h, w, 3) or not accum.flags.c_contiguous):
+        raise ValueError("accum must be contiguous float64 [H, W, 3]")
+    pc = capi.PtPostConfig(int(post.tonemap), int(post.denoise), post.sigma_s, post.sigma_r, int(post.smooth),
+                           post.smooth_radius, post.smooth_strength)
+    capi.check(L.pt_post_process(ctx.handle, C.byref(pc), _ptr(accum), samples_per_px, _ptr(img), int(img.strides[0]), w, h))
