@@ -9,9 +9,10 @@ from path_trace_golang_amd import capi, hip, scene
 ctx = capi.Context(ndev=1)
 L = capi.load()
 total = 0
-for name, w, h, spp, d in [("gpu_showcase", 1920, 1080, 32, 8), ("metal_glass_room", 1920, 1080, 32, 12),
-                           ("test_comprehensive", 1920, 1080, 16, 16), ("test_scene", 800, 600, 64, 8),
-                           ("example_simple", 400, 225, 64, 20)]:
+scale = int(os.environ.get("VERIFY_SCALE", "1"))
+for name, w, h, spp, d in [("gpu_showcase", 1920, 1080, 32 * scale, 8), ("metal_glass_room", 1920, 1080, 32 * scale, 12),
+                           ("test_comprehensive", 1920, 1080, 16 * scale, 16), ("test_scene", 800, 600, 64 * scale, 8),
+                           ("example_simple", 400, 225, 64 * scale, 20)]:
     sc = scene.load("scenes/%s.json" % name)
     img = np.zeros((h, w, 4), np.uint8)
     st = hip.render(sc, hip.RenderConfig(w, h, spp, d, 7), img, ctx=ctx)
