@@ -15,8 +15,8 @@
 //                     SCAN_BROAD    an FP32 broad phase over conservative (inflated) bounds
 //                                   builds a per-lane candidate bitmask, then each lane runs
 //                                   the exact FP64 tests only on its own candidates (per-lane
-//                                   look-ups in the LDS copy of the world).  Needs <= 64 objects.
-//                     SCAN_BVH      more than 64 objects: per-lane traversal of a binary BVH whose
+//                                   look-ups in the LDS copy of the world).  Needs <= 32 spheres and <= 32 boxes.
+//                     SCAN_BVH      larger scenes: per-lane traversal of a binary BVH whose
 //                                   FP32 node boxes are conservative (same inflation as the broad
 //                                   phase), exact FP64 tests at the leaves; nodes and objects are
 //                                   read from HBM/L2, the traversal stack lives in LDS.
@@ -1230,9 +1230,8 @@ __device__ __forceinline__ float aces_tonemap(float x) {
 }
 
 // gpu.go:2309-2350: clamp, ACES, sqrt gamma, uint8(g*255.0 + 0.5) in float32 arithmetic
-__global__ __launch_bounds__(PT_BLOCK) void post_tonemap_kernel(const double *__restrict__ accum, double inv_spp_is_unused,
-                                                                  int32_t spp, uint8_t *__restrict__ rgba, int32_t npix) {
-    (void)inv_spp_is_unused;
+__global__ __launch_bounds__(PT_BLOCK) void post_tonemap_kernel(const double *__restrict__ accum, int32_t spp,
+                                                                  uint8_t *__restrict__ rgba, int32_t npix) {
     const int32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (i >= npix) return;
     uint32_t packed = 255u << 24;

@@ -683,7 +683,7 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     F.nobj = (int32_t)sd.world.size();
     F.nmat = (int32_t)sd.mats.size();
     build_broad(sd.world, sd);
-    // closest-hit strategy: <= 64 objects -> candidate bitmask; more -> BVH.  PTCORE_SCAN overrides.
+    // closest-hit strategy: at most 32 spheres and 32 boxes -> candidate bitmasks; more -> BVH.  PTCORE_SCAN overrides.
     int scan = ctx->scan_mode;
     if (scan < 0) scan = F.broad_ok ? ptk::SCAN_BROAD : ptk::SCAN_BVH;
     if ((scan == ptk::SCAN_BROAD || scan == ptk::SCAN_VERIFY) && !F.broad_ok)
@@ -937,7 +937,7 @@ int32_t pt_post_process(pt_ctx *ctx, const pt_post_config *post, const double *a
     if (post->tonemap) {
         HIP_TRY(ctx->f_accum.reserve(npix * 3));
         HIP_TRY(hipMemcpyAsync(ctx->f_accum.p, accum, npix * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(ptk::post_tonemap_kernel, dim3(grid), dim3(PT_BLOCK), 0, s, ctx->f_accum.p, 0.0, spp, cur, (int32_t)npix);
+        hipLaunchKernelGGL(ptk::post_tonemap_kernel, dim3(grid), dim3(PT_BLOCK), 0, s, ctx->f_accum.p, spp, cur, (int32_t)npix);
         HIP_TRY(hipGetLastError());
     } else {
         HIP_TRY(hipMemcpy2DAsync(cur, (size_t)width * 4, rgba, (size_t)stride, (size_t)width * 4, (size_t)height,
