@@ -197,7 +197,9 @@ def main() -> int:
         if os.path.exists(tpath) and default_cfg:  # the PMC passes were taken on exactly this launch shape
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get("trace_kernel", {}).get("hbm_bytes_per_launch")
+                    tk = json.load(f).get("trace_kernel", {})
+                # PMC bytes per sample of a full-chunk launch x the samples of this run's average launch
+                traffic = tk["hbm_bytes_per_sample"] * jobs_per_launch if tk.get("hbm_bytes_per_sample") else None
             except Exception:
                 traffic = None
         objs = [o.type for o in sc.objects]

@@ -891,6 +891,17 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
         d.num_cu = prop.multiProcessorCount;
         d.stream = d.own_stream;
     }
+    // tile gather goes device -> devices[0] by peer DMA over xGMI: enable direct access where the
+    // topology offers it (without it hipMemcpyPeerAsync still works, staged through the host)
+    for (int i = 1; i < ndev; i++) {
+        const int a = ctx->devs[(size_t)i].ordinal, b = ctx->devs[0].ordinal;
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can && hipSetDevice(a) == hipSuccess) {
+            hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e != hipSuccess) (void)hipGetLastError();  // already enabled or refused: the copy path copes
+        }
+    }
     *out = ctx;
     return PT_OK;
 }

@@ -9,7 +9,7 @@ TAG=${1:-r01}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-SHORT="--spp 84 --steps 1 --warmup 0 --no-cpu-baseline"
+SHORT="--spp 200 --steps 1 --warmup 0 --no-cpu-baseline"   # 2 launches of one full 100-spp chunk each
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_under_trace.json 2> $OUT/trace.err || exit 1
 echo "trace pass done"
 i=0

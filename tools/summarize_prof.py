@@ -43,6 +43,14 @@ def g(c):
     return v[0] if v else 0.0  # launch 0 is a full spp chunk, the same shape as every launch of the full run
 
 
+jobs = None
+try:
+    import re
+    b3 = json.load(open(src + "/pmc3.json"))
+    m = re.search(r"(\d+)x(\d+), (\d+) spp", b3["config"]["workload"])
+    jobs = int(m.group(1)) * int(m.group(2)) * min(int(b3["config"]["spp_chunk"]), int(m.group(3)))
+except Exception as e:  # noqa: BLE001
+    out["jobs_error"] = str(e)
 if t:
     fetch_b = g("FETCH_SIZE") * 1024.0 * 2.0  # KB; x2: gfx950 FETCH_SIZE reports half of a wide coalesced read (guide, HBM section)
     write_b = g("WRITE_SIZE") * 1024.0
@@ -59,7 +67,8 @@ if t:
         "hbm_fetch_bytes_x2": fetch_b, "hbm_write_bytes": write_b,
     }
     json.dump({"trace_kernel": {"hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes_corrected_x2": fetch_b,
-                                "write_bytes": write_b,
+                                "write_bytes": write_b, "samples_in_measured_launch": jobs,
+                                "hbm_bytes_per_sample": (fetch_b + write_b) / jobs if jobs else None,
                                 "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                           "separate passes; FETCH_SIZE doubled per the gfx950 correction)" % tag}},
               open("profiles/pmc_traffic.json", "w"), indent=1)
