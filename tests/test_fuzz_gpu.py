@@ -1,0 +1,86 @@
+"""Randomised scenes through every closest-hit strategy (candidate bitmasks, BVH, plain scan) vs the oracle.
+Objects overlap, touch, nest, share centres and sizes on a coarse grid on purpose: exact ties and rays that
+start inside several objects are the cases where a culled strategy could differ from the sequential loop."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MAT_KINDS = ["lambert", "metal", "dielectric", "emissive", "mirror"]
+
+
+def _random_doc(rng, nobj):
+    mats = []
+    for i in range(rng.integers(1, 8)):
+        k = MAT_KINDS[int(rng.integers(len(MAT_KINDS)))]
+        m = {"id": "m%d" % i, "type": k, "albedo": dict(zip("rgb", rng.uniform(0.1, 1.0, 3).round(3).tolist())),
+             "rough": float(rng.choice([0.0, 0.0, 0.05, 0.5, 1.0])), "ior": float(rng.choice([0.0, 1.1, 1.5, 2.4])),
+             "emit": dict(zip("rgb", rng.uniform(0.2, 1.0, 3).round(3).tolist())), "power": float(rng.uniform(1, 8)),
+             "absorption": dict(zip("rgb", rng.choice([0.0, 0.0, 0.2, 1.0], 3).tolist())),
+             "smoothness": float(rng.choice([0.0, 0.0, 0.7, 1.0]))}
+        mats.append(m)
+    objs = []
+    grid = lambda lo, hi: float(rng.integers(lo * 2, hi * 2 + 1)) / 2.0  # half-unit grid: coincident faces are common
+    for i in range(nobj):
+        kind = rng.choice(["sphere", "box", "box", "sphere", "sphere_light", "plane"], p=[0.3, 0.25, 0.15, 0.15, 0.1, 0.05])
+        pos = {"x": grid(-3, 3), "y": grid(0, 4), "z": grid(-3, 3)}
+        if kind == "box":
+            size = {"x": grid(0, 3), "y": grid(0, 3), "z": grid(0, 3)}
+        else:
+            size = {"x": float(rng.choice([0.25, 0.5, 1.0, 1.5])), "y": 0, "z": 0}
+        objs.append({"id": "o%d" % i, "type": str(kind), "position": pos, "size": size,
+                     "material_id": "m%d" % int(rng.integers(len(mats) + 1))})  # sometimes a missing id
+    cam = {"position": {"x": grid(-2, 2), "y": grid(1, 3), "z": 7.0}, "target": {"x": 0, "y": 1.5, "z": 0},
+           "up": {"x": 0, "y": 1, "z": 0}, "fov": float(rng.choice([35, 60, 90])), "aperture": float(rng.choice([0, 0, 0.2])),
+           "focus_dist": float(rng.choice([0, 7])), "aspect_ratio": float(rng.choice([0, 1.7777778]))}
+    sky = [None, {"type": "gradient", "horizon": {"r": 1, "g": 1, "b": 1}, "zenith": {"r": 0.3, "g": 0.5, "b": 1}},
+           {"type": "solid", "color": {"r": 0.7, "g": 0.8, "b": 0.9}}][int(rng.integers(3))]
+    return {"camera": cam, "objects": objs, "materials": mats, "sky": sky, "background": {"r": 0.1, "g": 0.1, "b": 0.15}}
+
+
+@pytest.fixture(scope="module")
+def contexts():
+    from path_trace_golang_amd import capi
+
+    out = {}
+    old = os.environ.get("PTCORE_SCAN")
+    try:
+        for mode in ("broad", "bvh", "uniform"):
+            os.environ["PTCORE_SCAN"] = mode
+            out[mode] = capi.Context(ndev=1)
+    finally:
+        if old is None:
+            os.environ.pop("PTCORE_SCAN", None)
+        else:
+            os.environ["PTCORE_SCAN"] = old
+    yield out
+    for c in out.values():
+        c.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_all_strategies(contexts, oracle, seed):
+    from path_trace_golang_amd import capi, hip, scene
+
+    rng = np.random.default_rng(1000 + seed)
+    w, h, spp, depth = 32, 20, 3, 7
+    for _ in range(4):
+        doc = _random_doc(rng, int(rng.integers(1, 45)))
+        o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=seed + 1)
+        sc = scene.Scene.decode(doc)
+        for mode, ctx in contexts.items():
+            img = np.zeros((h, w, 4), np.uint8)
+            acc = np.zeros((h, w, 3))
+            nseg = np.zeros((h, w), np.uint32)
+            ndraw = np.zeros((h, w), np.uint32)
+            st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed + 1, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc,
+                            nseg, ndraw, ctx=ctx)
+            assert st["segments"] == o["stats"]["segments"], (mode, seed)
+            assert st["draws"] == o["stats"]["draws"] and st["exit_scans"] == o["stats"]["exit_scans"], (mode, seed)
+            assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]), (mode, seed)
+            assert np.array_equal(img, o["rgba"]), (mode, seed)
+            ref = o["accum"]
+            ok = (np.isnan(acc) & np.isnan(ref)) | (np.abs(acc - ref) <= 4 * depth * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
+            assert np.all(ok), (mode, seed)
