@@ -240,6 +240,7 @@ def main() -> int:
                               "unit": "Tflop/s (unfused)", "frac": fp64_tops / FP64_PEAK_NOFMA_TOPS,
                               "alg_flops_per_segment": fseg,
                               "trace_share_of_step": trace_ms / max(elapsed * 1e3, 1e-9),
+                              "raygen_ms_per_step": sum(s.raygen_ms for s in stats) / steps,
                               "resolve_ms_per_step": resolve_ms / steps},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -147,7 +147,7 @@ typedef struct pt_stats {
     uint64_t exit_scans; /* dielectric exit searches (renderer.go:316-371) */
     uint64_t draws;      /* RNG draws */
     double seconds;      /* host wall time of the call (upload + kernels + download) */
-    double trace_ms;     /* device time inside the trace kernel(s), HIP events */
+    double trace_ms;     /* device time inside the trace kernel(s) alone, HIP events around each launch */
     double resolve_ms;   /* device time inside the resolve kernel(s) */
     double device_ms;    /* device time first launch -> last launch complete */
     int32_t trace_launches;
@@ -155,6 +155,7 @@ typedef struct pt_stats {
     int32_t spp_chunk;   /* chunk actually used */
     int32_t num_devices;
     double per_device_ms[8];
+    double raygen_ms;    /* device time inside the ray-generation kernel(s) */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

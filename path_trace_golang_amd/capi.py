@@ -71,7 +71,7 @@ class PtStats(C.Structure):
                 ("draws", C.c_uint64), ("seconds", C.c_double), ("trace_ms", C.c_double),
                 ("resolve_ms", C.c_double), ("device_ms", C.c_double), ("trace_launches", C.c_int32),
                 ("resolve_launches", C.c_int32), ("spp_chunk", C.c_int32), ("num_devices", C.c_int32),
-                ("per_device_ms", C.c_double * 8)]
+                ("per_device_ms", C.c_double * 8), ("raygen_ms", C.c_double)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "per_device_ms"}

@@ -147,7 +147,7 @@ struct TraceBuffers {
     const double *ray;    // [6][njobs] primary rays of the chunk (raygen_kernel)
     const unsigned long long *ray_rng;  // [njobs] stream state after the camera draws
     const uint16_t *ray_ndraw;          // [njobs] draws used by ray generation; 0xffff = pixel outside the frame
-    double *L;            // [3][njobs]
+    double *L;            // [njobs][4]: r, g, b, 0 (one 32-byte record per job)
     uint32_t *job_seg;    // [njobs] or null (PT_FLAG_PIXEL_STATS)
     uint32_t *job_draw;   // [njobs] or null
     unsigned int *queue;  // job queue head

@@ -1045,9 +1045,9 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
 
             if (finished) {
                 SEC_BEGIN(SEC_FINISH)
-                B.L[job] = Tx * termx;
-                B.L[(size_t)F.njobs + job] = Ty * termy;
-                B.L[2 * (size_t)F.njobs + job] = Tz * termz;
+                // one whole 32-byte record per job: lanes finish at different times, so a [3][njobs] layout
+                // would dirty three partly written sectors per job
+                reinterpret_cast<double4 *>(B.L)[job] = make_double4(Tx * termx, Ty * termy, Tz * termz, 0.0);
                 if (STATS) {
                     B.job_seg[job] = j_seg;
                     B.job_draw[job] = j_draw;
@@ -1094,7 +1094,7 @@ __device__ __forceinline__ uint32_t quantise(double v) {
 }
 
 struct ResolveArgs {
-    const double *L;         // [3][njobs]
+    const double *L;         // [njobs][4]: r, g, b, 0
     const uint32_t *job_seg; // [njobs] or null
     const uint32_t *job_draw;
     double *acc;             // [3][nslots]
@@ -1138,9 +1138,10 @@ __global__ __launch_bounds__(PT_BLOCK) void resolve_kernel(const ResolveArgs R) 
             const size_t base = (size_t)blk * R.S * 64u + p;
             for (uint32_t s = 0; s < R.S; s++) {  // col = col.add(sample), renderer.go:186, in sample order
                 const size_t j = base + (size_t)s * 64u;
-                cx += R.L[j];
-                cy += R.L[(size_t)R.njobs + j];
-                cz += R.L[2 * (size_t)R.njobs + j];
+                const double4 l = reinterpret_cast<const double4 *>(R.L)[j];
+                cx += l.x;
+                cy += l.y;
+                cz += l.z;
                 if (R.job_seg) { nseg += R.job_seg[j]; ndraw += R.job_draw[j]; }
             }
             R.acc[slot] = cx;

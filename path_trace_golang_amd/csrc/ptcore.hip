@@ -98,8 +98,8 @@ struct Device {
     DevBuf<unsigned int> queue;
     DevBuf<unsigned long long> counters;
     DevBuf<unsigned long long> prof;
-    std::vector<EventPair> ev_trace, ev_resolve;
-    size_t n_trace = 0, n_resolve = 0;
+    std::vector<EventPair> ev_trace, ev_resolve, ev_raygen;
+    size_t n_trace = 0, n_resolve = 0, n_raygen = 0;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     bool first_recorded = false;
     // frame state
@@ -444,7 +444,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
     d.nlocal = tiles_of_shard(fr.ntx * fr.nty, shard);
     d.nslots = (uint32_t)d.nlocal * 1024u;
     d.acc_started = false;
-    d.n_trace = d.n_resolve = 0;
+    d.n_trace = d.n_resolve = d.n_raygen = 0;
     d.first_recorded = false;
     if (d.scene_gen != sd.gen) {
         HIP_TRY(d.objs.reserve(std::max<size_t>(1, world.size())));
@@ -484,7 +484,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         HIP_TRY(d.acc_draw.reserve(ns));
     }
     const size_t njobs_max = (size_t)ns * fr.chunk;
-    HIP_TRY(d.L.reserve(3 * njobs_max));
+    HIP_TRY(d.L.reserve(4 * njobs_max));
     HIP_TRY(d.ray.reserve(6 * njobs_max));
     HIP_TRY(d.ray_rng.reserve(njobs_max));
     HIP_TRY(d.ray_ndraw.reserve(njobs_max));
@@ -543,7 +543,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     }
     if (fr.cfg.max_depth <= 0) {
         // rayColorOpt returns black at depth <= 0 (renderer.go:287-289): nothing to trace
-        HIP_TRY(hipMemsetAsync(d.L.p, 0, 3 * (size_t)F.njobs * sizeof(double), d.stream));
+        HIP_TRY(hipMemsetAsync(d.L.p, 0, 4 * (size_t)F.njobs * sizeof(double), d.stream));
         if (fr.stats_on) {
             HIP_TRY(hipMemsetAsync(d.job_seg.p, 0, (size_t)F.njobs * sizeof(uint32_t), d.stream));
             HIP_TRY(hipMemsetAsync(d.job_draw.p, 0, (size_t)F.njobs * sizeof(uint32_t), d.stream));
@@ -554,10 +554,15 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
         const uint32_t waves_needed = (F.njobs + 63u) / 64u;
         uint32_t grid = (uint32_t)(d.num_cu * d.blocks_per_cu);
         grid = std::max(1u, std::min(grid, (waves_needed + 3u) / 4u));
-        EventPair &e = d.ev_trace[d.n_trace++];
-        HIP_TRY(hipEventRecord(e.a, d.stream));
+        if (int32_t rc = dev_events(d, d.ev_raygen, d.n_raygen + 1)) return rc;
+        EventPair &eg = d.ev_raygen[d.n_raygen++];
+        HIP_TRY(hipEventRecord(eg.a, d.stream));
         hipLaunchKernelGGL(ptk::raygen_kernel, dim3((F.njobs + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, d.stream, F, fr.cam,
                            d.ray.p, d.ray_rng.p, d.ray_ndraw.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(eg.b, d.stream));
+        EventPair &e = d.ev_trace[d.n_trace++];
+        HIP_TRY(hipEventRecord(e.a, d.stream));
         hipLaunchKernelGGL(pick_trace(fr.stats_on, ctx->profile_sections, fr.scan), dim3(grid), dim3(PT_BLOCK), lds, d.stream, F,
                            fr.sky, B);
         HIP_TRY(hipGetLastError());
@@ -652,6 +657,13 @@ int32_t dev_collect(Device &d, pt_stats *st, int slot) {
         HIP_TRY(hipEventElapsedTime(&ms, d.ev_resolve[i].a, d.ev_resolve[i].b));
         rs += ms;
     }
+    double rg = 0;
+    for (size_t i = 0; i < d.n_raygen; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d.ev_raygen[i].a, d.ev_raygen[i].b));
+        rg += ms;
+    }
+    st->raygen_ms = std::max(st->raygen_ms, rg);
     float span = 0;
     if (d.first_recorded) HIP_TRY(hipEventElapsedTime(&span, d.ev_first, d.ev_last));
     st->trace_ms = std::max(st->trace_ms, tr);
@@ -810,7 +822,7 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     // chunk of samples per pass: bounded by the L budget and by 2^31 jobs
     uint32_t chunk = cfg->spp_chunk > 0 ? (uint32_t)cfg->spp_chunk : 0;
     const uint32_t slots = std::max(1u, max_slots);
-    if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * 82));  // 24 B radiance + 58 B primary ray per job
+    if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * 90));  // 32 B radiance record + 58 B primary ray per job
     chunk = std::min<uint32_t>(chunk, (uint32_t)std::max(1, cfg->samples_per_px));
     chunk = std::min<uint32_t>(chunk, std::max(1u, 0x7fffffffu / slots));
     fr.chunk = chunk;
@@ -919,6 +931,7 @@ void pt_destroy(pt_ctx *ctx) {
         d.counters.release();
         for (EventPair &e : d.ev_trace) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (EventPair &e : d.ev_resolve) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (EventPair &e : d.ev_raygen) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (d.ev_first) (void)hipEventDestroy(d.ev_first);
         if (d.ev_last) (void)hipEventDestroy(d.ev_last);
         if (d.own_stream) (void)hipStreamDestroy(d.own_stream);

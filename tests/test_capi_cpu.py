@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.PtSky) == 8 + 12 * 8
     assert C.sizeof(capi.PtScene) == 13 * 8 + 104 + 8 + 16
     assert C.sizeof(capi.PtConfig) == 32
-    assert C.sizeof(capi.PtStats) == 4 * 8 + 4 * 8 + 4 * 4 + 8 * 8
+    assert C.sizeof(capi.PtStats) == 4 * 8 + 4 * 8 + 4 * 4 + 8 * 8 + 8
 
 
 def test_no_device_is_an_error_not_a_fallback():
