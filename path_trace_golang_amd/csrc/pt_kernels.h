@@ -324,16 +324,20 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         const float qx = __builtin_fmaf(fdx, tca, ocx), qy = __builtin_fmaf(fdy, tca, ocy), qz = __builtin_fmaf(fdz, tca, ocz);
         const float d2 = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
         const float rem = s.rm2 - d2;  // >= 0: the line passes within the inflated radius
-        const float u = tminf - tca;   // > 0: closest approach lies before tMin
-        const bool miss = (rem < 0.0f) || ((u > 0.0f) && (u * u * fa > rem));  // outside, or wholly behind
+        const float w = __builtin_fmaxf(tminf - tca, 0.0f);  // > 0: closest approach lies before tMin
+        // outside (rem < 0) or wholly behind (w^2 a > rem) in one compare, as w^2 a >= 0; NaN keeps the sphere
+        const bool miss = rem < w * w * fa;
         cs = miss ? cs : (cs | (1u << k));
     }
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
+    // slab parameters as lo * (1/d) - o/d: one fma each; the extra rounding (~2^-24 |o| in distance) is far inside
+    // the margin, and inf - inf = NaN for a zero direction component leaves that slab unconstrained
+    const float noxf = -fox * ivxf, noyf = -foy * ivyf, nozf = -foz * ivzf;
     for (int k = 0; k < F.n_bbox; k++) {
         const auto &bx = g_bb[k];
-        const float tax = (bx.lo[0] - fox) * ivxf, tbx = (bx.hi[0] - fox) * ivxf;
-        const float tay = (bx.lo[1] - foy) * ivyf, tby = (bx.hi[1] - foy) * ivyf;
-        const float taz = (bx.lo[2] - foz) * ivzf, tbz = (bx.hi[2] - foz) * ivzf;
+        const float tax = __builtin_fmaf(bx.lo[0], ivxf, noxf), tbx = __builtin_fmaf(bx.hi[0], ivxf, noxf);
+        const float tay = __builtin_fmaf(bx.lo[1], ivyf, noyf), tby = __builtin_fmaf(bx.hi[1], ivyf, noyf);
+        const float taz = __builtin_fmaf(bx.lo[2], ivzf, nozf), tbz = __builtin_fmaf(bx.hi[2], ivzf, nozf);
         // v_min/v_max return the other operand for a NaN: a NaN slab (0 * inf) constrains nothing
         const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)),
                                          __builtin_fmaxf(__builtin_fminf(taz, tbz), tminf));
