@@ -1,14 +1,17 @@
-// pt_bvh.h -- host-side BVH builder for scenes with more than 64 finite objects.
+// pt_bvh.h -- host-side BVH builder for scenes beyond the 32+32-object candidate bitmasks.
 //
 // The reference scans every object for every ray segment (renderer.go:297-302).  Its winner is
 // an order-free function of the per-object hit distances (see `wins` in pt_kernels.h), so any
 // structure that never skips an object the exact test would accept returns the same winner.  The
 // hierarchy stores FP32 boxes inflated by the same margin as the flat broad phase and rounded
-// outward; the exact FP64 tests run only at the leaves.
+// outward; the exact FP64 tests run only on objects whose own FP32 box the ray pierces.
 //
-// Layout: binary tree, each 64-byte node carries BOTH children's boxes (one node fetch decides
-// both descents); leaves hold up to LEAF_MAX objects, which are stored contiguously in leaf order
-// (80-byte DevObj + original index) so a leaf is one contiguous read.
+// Build: binned-SAH binary tree down to single objects, then collapsed into 4-wide nodes (the
+// child with the largest box is replaced by its two children until the node has four).  A slot
+// of a wide node is an internal node, one object, or empty.  Nodes are numbered breadth-first, so
+// the internal children of a node are consecutive (node_base + rank), its object children are
+// consecutive in the object array (obj_base + rank), and the top of the tree is one prefix that
+// the kernel stages in LDS.
 #pragma once
 
 #include <algorithm>
@@ -23,7 +26,7 @@ namespace ptbvh {
 
 using namespace ptd;
 
-constexpr int LEAF_MAX = 4;
+constexpr int WIDTH = 4;
 
 struct Aabb {
     double lo[3], hi[3];
@@ -56,9 +59,10 @@ inline Aabb object_bounds(const DevObj &o) {
 }
 
 struct Built {
-    std::vector<BvhNode> nodes;      // nodes[0] is the root (present even for 1 object)
-    std::vector<int32_t> order;      // leaf order -> index into the world array
-    int depth = 0;
+    std::vector<BvhNode> nodes;      // nodes[0] is the root (present whenever there is an object)
+    std::vector<int32_t> order;      // object slot -> index into the world array
+    int depth = 0;                   // levels of wide nodes
+    int stack_need = 0;              // most internal-node entries a traversal can have pushed at once
 };
 
 namespace detail {
@@ -74,24 +78,18 @@ inline float up(double v) {
     return f;
 }
 
+struct BinNode {
+    Aabb box;
+    int32_t left = -1, right = -1;  // both -1: leaf
+    int32_t obj = -1;               // leaf: world index
+};
+
 struct Builder {
     const std::vector<Aabb> &bounds;
     std::vector<double> cx[3];
-    std::vector<int32_t> &idx;
-    std::vector<BvhNode> &nodes;
+    std::vector<int32_t> idx;       // working permutation of the object list
+    std::vector<BinNode> bin;
     double margin;
-    int max_depth = 0;
-
-    Aabb range_bounds(int a, int b) const {
-        Aabb r;
-        r.reset();
-        for (int i = a; i < b; i++) r.grow(bounds[(size_t)idx[(size_t)i]]);
-        return r;
-    }
-    void put_box(float *lo, float *hi, const Aabb &b) const {
-        for (int k = 0; k < 3; k++) { lo[k] = down(b.lo[k] - margin); hi[k] = up(b.hi[k] + margin); }
-    }
-    static int32_t leaf_code(int first, int count) { return ~(int32_t)((uint32_t)first | ((uint32_t)(count - 1) << 28)); }
 
     // chooses the split position inside [a, b): binned SAH over the largest centroid axis, median fallback
     int split(int a, int b) {
@@ -111,47 +109,44 @@ struct Builder {
         }
         const int mid = (a + b) / 2;
         auto by_axis = [&](int32_t u, int32_t v) { return cx[axis][(size_t)u] < cx[axis][(size_t)v]; };
-        if (!(ext > 0)) {
-            return mid;  // all centroids coincide (or are not finite): any split is as good
-        }
+        if (!(ext > 0)) return mid;  // all centroids coincide (or are not finite): any split is as good
         constexpr int NB = 16;
         Aabb bb[NB];
         int cnt[NB];
         for (int i = 0; i < NB; i++) { bb[i].reset(); cnt[i] = 0; }
         const double scale = NB / ext;
+        auto bin_of = [&](int32_t o) {
+            const int q = (int)((cx[axis][(size_t)o] - cb.lo[axis]) * scale);
+            return std::max(0, std::min(NB - 1, q));
+        };
         for (int i = a; i < b; i++) {
             const int32_t o = idx[(size_t)i];
-            int bin = (int)((cx[axis][(size_t)o] - cb.lo[axis]) * scale);
-            bin = std::max(0, std::min(NB - 1, bin));
-            bb[bin].grow(bounds[(size_t)o]);
-            cnt[bin]++;
+            const int q = bin_of(o);
+            bb[q].grow(bounds[(size_t)o]);
+            cnt[q]++;
         }
         double best = INFINITY;
         int best_bin = -1;
-        Aabb left[NB], right[NB];
-        int lc[NB], rc[NB];
+        Aabb right[NB];
+        int rc[NB];
         Aabb acc;
         acc.reset();
         int n = 0;
-        for (int i = 0; i < NB; i++) { acc.grow(bb[i]); n += cnt[i]; left[i] = acc; lc[i] = n; }
+        for (int i = NB - 1; i >= 0; i--) { acc.grow(bb[i]); n += cnt[i]; right[i] = acc; rc[i] = n; }
         acc.reset();
         n = 0;
-        for (int i = NB - 1; i >= 0; i--) { acc.grow(bb[i]); n += cnt[i]; right[i] = acc; rc[i] = n; }
         for (int i = 0; i + 1 < NB; i++) {
-            if (lc[i] == 0 || rc[i + 1] == 0) continue;
-            const double cost = left[i].area() * lc[i] + right[i + 1].area() * rc[i + 1];
+            acc.grow(bb[i]);
+            n += cnt[i];
+            if (n == 0 || rc[i + 1] == 0) continue;
+            const double cost = acc.area() * n + right[i + 1].area() * rc[i + 1];
             if (cost < best) { best = cost; best_bin = i; }
         }
-        if (best_bin < 0 || !std::isfinite(best)) {
-            std::nth_element(idx.begin() + a, idx.begin() + mid, idx.begin() + b, by_axis);
-            return mid;
+        int m = mid;
+        if (best_bin >= 0 && std::isfinite(best)) {
+            auto it = std::partition(idx.begin() + a, idx.begin() + b, [&](int32_t o) { return bin_of(o) <= best_bin; });
+            m = (int)(it - idx.begin());
         }
-        auto it = std::partition(idx.begin() + a, idx.begin() + b, [&](int32_t o) {
-            int bin = (int)((cx[axis][(size_t)o] - cb.lo[axis]) * scale);
-            bin = std::max(0, std::min(NB - 1, bin));
-            return bin <= best_bin;
-        });
-        int m = (int)(it - idx.begin());
         if (m <= a || m >= b) {
             std::nth_element(idx.begin() + a, idx.begin() + mid, idx.begin() + b, by_axis);
             m = mid;
@@ -159,26 +154,51 @@ struct Builder {
         return m;
     }
 
-    // returns the child code of the subtree over idx[a, b)
-    int32_t build(int a, int b, int depth) {
-        max_depth = std::max(max_depth, depth);
-        const int n = b - a;
-        if (n <= LEAF_MAX) return leaf_code(a, n);
-        const int m = split(a, b);
-        const int32_t me = (int32_t)nodes.size();
-        nodes.emplace_back();
-        {
-            BvhNode nd;
-            std::memset(&nd, 0, sizeof nd);
-            put_box(nd.lo0, nd.hi0, range_bounds(a, m));
-            put_box(nd.lo1, nd.hi1, range_bounds(m, b));
-            nodes[(size_t)me] = nd;
+    // binary tree over idx[a, b); returns its node
+    int32_t build(int a, int b) {
+        const int32_t me = (int32_t)bin.size();
+        bin.emplace_back();
+        if (b - a == 1) {
+            bin[(size_t)me].obj = idx[(size_t)a];
+            bin[(size_t)me].box = bounds[(size_t)idx[(size_t)a]];
+            return me;
         }
-        const int32_t c0 = build(a, m, depth + 1);
-        const int32_t c1 = build(m, b, depth + 1);
-        nodes[(size_t)me].c0 = c0;
-        nodes[(size_t)me].c1 = c1;
+        const int m = split(a, b);
+        const int32_t l = build(a, m);
+        const int32_t r = build(m, b);
+        BinNode &nd = bin[(size_t)me];
+        nd.left = l;
+        nd.right = r;
+        nd.box = bin[(size_t)l].box;
+        nd.box.grow(bin[(size_t)r].box);
         return me;
+    }
+
+    // the (up to WIDTH) binary nodes that become the slots of the wide node made from binary node b
+    int gather(int32_t b, int32_t out[WIDTH]) const {
+        int n = 0;
+        if (bin[(size_t)b].obj >= 0) {  // a tree of one object: the root holds it in slot 0
+            out[n++] = b;
+            return n;
+        }
+        out[n++] = bin[(size_t)b].left;
+        out[n++] = bin[(size_t)b].right;
+        while (n < WIDTH) {
+            int pick = -1;
+            double area = -1;
+            for (int k = 0; k < n; k++) {
+                const BinNode &c = bin[(size_t)out[k]];
+                if (c.obj >= 0) continue;
+                double ar = c.box.area();
+                if (!(ar == ar)) ar = INFINITY;  // unbounded boxes first
+                if (ar > area) { area = ar; pick = k; }
+            }
+            if (pick < 0) break;
+            const BinNode &c = bin[(size_t)out[pick]];
+            out[pick] = c.left;
+            out[n++] = c.right;
+        }
+        return n;
     }
 };
 
@@ -187,9 +207,10 @@ struct Builder {
 // `finite` lists the world indices of the spheres and boxes (planes stay outside the tree).
 inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> &finite, double margin) {
     Built out;
-    out.order = finite;
+    const int n = (int)finite.size();
+    if (n == 0) return out;  // no finite objects: the kernel skips the traversal
     std::vector<Aabb> bounds(world.size());
-    detail::Builder bl{bounds, {}, out.order, out.nodes, margin};
+    detail::Builder bl{bounds, {}, finite, {}, margin};
     for (int k = 0; k < 3; k++) bl.cx[k].assign(world.size(), 0.0);
     for (int32_t i : finite) {
         bounds[(size_t)i] = object_bounds(world[(size_t)i]);
@@ -199,29 +220,59 @@ inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> 
             bl.cx[k][(size_t)i] = c;
         }
     }
-    const int n = (int)finite.size();
-    if (n == 0) return out;  // no finite objects: the kernel skips the traversal
-    if (n <= LEAF_MAX) {
-        // too few objects for a split by the builder: one root over two leaves (the same leaf twice
-        // when there is a single object; testing an object twice cannot change the winner)
-        const int m = n > 1 ? n / 2 : 1;
+    bl.bin.reserve((size_t)2 * n);
+    const int32_t root = bl.build(0, n);
+
+    // breadth-first collapse: queue entry = binary node that becomes wide node number q
+    std::vector<int32_t> queue{root};
+    std::vector<int32_t> level{1};
+    out.order.reserve((size_t)n);
+    for (size_t q = 0; q < queue.size(); q++) {
+        int32_t slot[WIDTH];
+        const int ns = bl.gather(queue[q], slot);
         BvhNode nd;
         std::memset(&nd, 0, sizeof nd);
-        bl.put_box(nd.lo0, nd.hi0, bl.range_bounds(0, m));
-        nd.c0 = detail::Builder::leaf_code(0, m);
-        if (n > 1) {
-            bl.put_box(nd.lo1, nd.hi1, bl.range_bounds(m, n));
-            nd.c1 = detail::Builder::leaf_code(m, n - m);
-        } else {
-            bl.put_box(nd.lo1, nd.hi1, bl.range_bounds(0, 1));
-            nd.c1 = detail::Builder::leaf_code(0, 1);
+        nd.node_base = (int32_t)queue.size();
+        nd.obj_base = (int32_t)out.order.size();
+        uint32_t ranks = 0, intm = 0, objm = 0;
+        int ni = 0, no = 0;
+        for (int s = 0; s < WIDTH; s++) {
+            if (s >= ns) {  // empty slot: never flagged in the masks; the box is a far-away point
+                for (int k = 0; k < 3; k++) { nd.lo[k][s] = 3.0e38f; nd.hi[k][s] = 3.0e38f; }
+                continue;
+            }
+            const detail::BinNode &c = bl.bin[(size_t)slot[s]];
+            for (int k = 0; k < 3; k++) {
+                nd.lo[k][s] = detail::down(c.box.lo[k] - margin);
+                nd.hi[k][s] = detail::up(c.box.hi[k] + margin);
+            }
+            if (c.obj >= 0) {
+                ranks |= (uint32_t)no << (2 * s);
+                objm |= 1u << s;
+                out.order.push_back(c.obj);
+                no++;
+            } else {
+                ranks |= (uint32_t)ni << (2 * s);
+                intm |= 1u << s;
+                queue.push_back(slot[s]);
+                level.push_back(level[q] + 1);
+                ni++;
+            }
         }
+        nd.meta = ranks | (intm << 8) | (objm << 12);
         out.nodes.push_back(nd);
-        out.depth = 1;
-        return out;
+        out.depth = std::max(out.depth, level[q]);
     }
-    bl.build(0, n, 1);
-    out.depth = bl.max_depth;
+    // deepest stack: a node with k internal children leaves at most k-1 entries below the subtree being walked
+    std::vector<int32_t> need(out.nodes.size(), 0);
+    for (size_t q = out.nodes.size(); q-- > 0;) {
+        const BvhNode &nd = out.nodes[q];
+        const int k = __builtin_popcount((nd.meta >> 8) & 0xfu);
+        int deepest = 0;
+        for (int c = 0; c < k; c++) deepest = std::max(deepest, need[(size_t)(nd.node_base + c)]);
+        need[q] = k > 0 ? (k - 1) + deepest : 0;
+    }
+    out.stack_need = need[0];
     return out;
 }
 

@@ -65,18 +65,23 @@ struct alignas(16) BroadBox {
 };
 static_assert(sizeof(BroadBox) == 32, "BroadBox layout");
 
-// BVH node for scenes beyond the 64-object bitmask: both children's FP32 boxes (inflated, rounded
-// outward) in one 64-byte record.  Child codes: >= 0 internal node index; < 0 leaf, with
-// ~code = first | (count-1) << 28 into the leaf-ordered object array.
-struct alignas(64) BvhNode {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
-    int32_t c0, c1;
-    int32_t flags, pad;
+// BVH node for scenes beyond the candidate bitmasks: four slots, each an internal node, one object or
+// empty, with the slot's FP32 box (inflated, rounded outward) stored slot-minor so one 16-byte load
+// brings the same bound of all four.  Nodes are numbered breadth-first: the internal children of a
+// node are node_base + rank, its object children bvh_objs[obj_base + rank].
+//   meta bits 0-7: rank of slot s within its kind at bits [2s, 2s+2); 8-11: slot is an internal node;
+//   12-15: slot is an object.
+struct alignas(16) BvhNode {
+    float lo[3][4];   // [axis][slot]
+    float hi[3][4];
+    int32_t node_base;
+    int32_t obj_base;
+    uint32_t meta;
+    int32_t pad;
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode layout");
+static_assert(sizeof(BvhNode) == 112, "BvhNode layout");
 
-// Object as stored in leaf order for the BVH path: the 80-byte DevObj plus its index in file order
+// Object as stored in node order for the BVH path: the 80-byte DevObj plus its index in file order
 // (tie rules and the winner look-up use the original index).
 struct alignas(16) BvhObj {
     DevObj o;

@@ -97,7 +97,7 @@ enum { SEC_ITER = 0, SEC_RAYGEN, SEC_LENS, SEC_SCAN, SEC_SPH_ROOT, SEC_SPH_ROOT2
 
 
 enum { SCAN_UNIFORM = 0, SCAN_BROAD = 1, SCAN_VERIFY = 2, SCAN_BVH = 3, SCAN_VERIFY_BVH = 4 };
-#define PT_BVH_STACK 48  // upper bound of the depth-sized per-lane stack
+#define PT_BVH_STACK 96  // upper bound of the per-lane stack (sized per scene from the tree)
 
 // Diagnostic hooks handed to the scan routines (all no-ops unless PROF).
 struct ProfHooks {
@@ -227,32 +227,44 @@ __device__ __forceinline__ void scan_uniform(const DevFrame &F, ObjPtr g_obj, co
 //   inside   : the origin is in the cube (ts = 0, nothing else to do)
 //   miss     : the ray never is inside the cube at a parameter >= tmin  -> no sphere or box can be hit
 //   te, ts   : entry parameter; the FP32 tests run from the entry point o + d*ts (parameters relative to ts)
-//   far      : the origin is so far out (more than ~2000 scene sizes) that the REFERENCE's own FP64 tests
-//              lose their meaning there: halfB*halfB - a*c cancels catastrophically and "hits" appear
-//              well outside the geometry.  Culling by geometry would drop those bit-exact artefacts, so
-//              such rays take the plain every-object scan.
+//   far      : the origin is so far out (more than ~2000 scene sizes) that the REFERENCE's own FP64 sphere
+//              test loses its meaning there: halfB*halfB - a*c cancels and carries an error of a few
+//              2^-53 a |oc|^2, so it reports "hits" on spheres the line passes within
+//              delta ~ 3e-8 |oc| of.  Culling by the true geometry would drop those bit-exact artefacts.
+//              The bitmask strategy sends such rays through the plain every-object scan; the BVH widens
+//              every bound by `infl` = 4 delta for them (and the cube here by the same), which keeps every
+//              object the reference's test can accept.  The slab test of a box has no such cancellation.
 // v_min/v_max skip the NaN of a 0 * inf slab boundary, which leaves that slab unconstrained: conservative.
 struct Clip {
-    double ts, te;
+    double ts, te, infl;
     bool miss, far;
 };
 __device__ __forceinline__ Clip clip_ray(const DevFrame &F, const RayD &r, double tmin) {
-    Clip c{0.0, 0.0, false, false};
-    const double Bs = F.scene_bound;
+    Clip c{0.0, 0.0, 0.0, false, false};
+    double Bs = F.scene_bound;
     if (!(ptm::f_abs(r.ox) <= Bs && ptm::f_abs(r.oy) <= Bs && ptm::f_abs(r.oz) <= Bs)) {
         const double ix = 1 / r.dx, iy = 1 / r.dy, iz = 1 / r.dz;
-        const double x0 = (-Bs - r.ox) * ix, x1 = (Bs - r.ox) * ix;
-        const double y0 = (-Bs - r.oy) * iy, y1 = (Bs - r.oy) * iy;
-        const double z0 = (-Bs - r.oz) * iz, z1 = (Bs - r.oz) * iz;
-        const double te = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmin(z0, z1));
-        const double tx = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmax(z0, z1));
+        double te, tx;
+        auto cube = [&]() {
+            const double x0 = (-Bs - r.ox) * ix, x1 = (Bs - r.ox) * ix;
+            const double y0 = (-Bs - r.oy) * iy, y1 = (Bs - r.oy) * iy;
+            const double z0 = (-Bs - r.oz) * iz, z1 = (Bs - r.oz) * iz;
+            te = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmin(z0, z1));
+            tx = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmax(z0, z1));
+        };
+        cube();
+        const double reach = ptm::f_abs(r.ox) + ptm::f_abs(r.oy) + ptm::f_abs(r.oz) +
+                             (ptm::f_abs(r.dx) + ptm::f_abs(r.dy) + ptm::f_abs(r.dz)) * ptm::f_abs(te);
+        // delta must stay far inside the margin m that every bound already has
+        c.far = !(reach * 3.0e-8 <= F.margin * 0.25);
+        if (c.far) {
+            c.infl = reach * 1.2e-7;
+            Bs += c.infl;
+            cube();
+        }
         c.miss = te > tx || tx < tmin;
         c.te = te;
         c.ts = (te > 0 && !c.miss) ? te : 0;
-        const double reach = ptm::f_abs(r.ox) + ptm::f_abs(r.oy) + ptm::f_abs(r.oz) +
-                             (ptm::f_abs(r.dx) + ptm::f_abs(r.dy) + ptm::f_abs(r.dz)) * ptm::f_abs(te);
-        // error of the reference's sphere discriminant in distance^2: ~2^-50 reach^2; it must stay far inside m^2
-        c.far = !(reach * 3.0e-8 <= F.margin * 0.25);
     }
     return c;
 }
@@ -395,7 +407,9 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
 
 // Closest hit / exit search through the BVH.  Traversal order and culling only decide which
 // objects get the exact test; `wins` makes the result independent of that order.
-template <bool PROF, typename ObjPtr, typename IdxPtr>
+// FAR: some lane of the wave carries clip.infl > 0 (see clip_ray); every node and object bound is then
+// widened by the lane's own infl.
+template <bool PROF, bool FAR, typename ObjPtr, typename IdxPtr>
 __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr g_pl, const BvhNode *__restrict__ nodes,
                                          const BvhNode *lds_nodes /* nodes[0 .. F.bvh_lds_nodes) staged in LDS */,
                                          const BvhObj *__restrict__ bobjs, int *stack /* this lane's column, stride PT_BLOCK */,
@@ -439,67 +453,102 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     float tminf = (float)((mode ? 0.0001 : 0.001) - ts);
     tminf -= __builtin_fabsf(tminf) * 1e-2f + 1e-6f;  // a little below tMin - ts
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
+    // slab parameters as bound * (1/d) - o/d (see scan_broad_narrow)
+    const float noxf = -fox * ivxf, noyf = -foy * ivyf, nozf = -foz * ivzf;
+    // widening of a slab by infl in parameter units (a little more than infl / |d|; inf or NaN for a zero
+    // component, which unconstrains the slab)
+    const float inflf = FAR ? (float)clip.infl * 1.0001f : 0.0f;
+    const float exf = inflf * __builtin_fabsf(ivxf), eyf = inflf * __builtin_fabsf(ivyf), ezf = inflf * __builtin_fabsf(ivzf);
     float tmaxf = (float)(tmax - ts);
     tmaxf += __builtin_fabsf(tmaxf) * 4.8e-7f;  // >= tmax - ts (MaxFloat64 becomes +inf)
     int sp = 0;
-    int cur = root;
-    const int DONE = 0x7fffffff;
-    uint32_t n_leaf = 0;  // PROF only: leaves this lane visited
+    int cur = root;            // node to visit next, -1 when this lane has none left
+    uint32_t pend = 0;         // slots of the last visited node whose object still awaits its exact test
+    uint32_t pend_meta = 0;
+    int pend_base = 0;
+    uint32_t n_leaf = 0;  // PROF only: object batches this lane went through
     PH_BEGIN(SEC_BROAD)
-    while (__ballot(cur != DONE) != 0) {
-        // ---- descend through internal nodes until this lane sits on a leaf (or is done)
-        while (cur >= 0 && cur != DONE) {
+    while (__ballot(cur >= 0) != 0) {
+        // ---- walk internal nodes until this lane holds objects to test (or has nothing left)
+        while (cur >= 0) {
             if (PROF) ph.lanes[SEC_NBOX]++;  // node visits (lane count)
             BvhNode nd;
             if (cur < F.bvh_lds_nodes) nd = lds_nodes[cur];  // top of the tree: LDS packet
             else nd = nodes[cur];                            // below: HBM / L2
-            float t0a, t0b;
-            bool h0, h1;
-            {
-                const float tax = (nd.lo0[0] - fox) * ivxf, tbx = (nd.hi0[0] - fox) * ivxf;
-                const float tay = (nd.lo0[1] - foy) * ivyf, tby = (nd.hi0[1] - foy) * ivyf;
-                const float taz = (nd.lo0[2] - foz) * ivzf, tbz = (nd.hi0[2] - foz) * ivzf;
-                t0a = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)),
-                                      __builtin_fmaxf(__builtin_fminf(taz, tbz), tminf));
-                const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
-                                                 __builtin_fminf(__builtin_fmaxf(taz, tbz), tmaxf));
-                h0 = !(t1 < t0a);
+            float t0[4];
+            uint32_t hb = 0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const float tax = __builtin_fmaf(nd.lo[0][s], ivxf, noxf), tbx = __builtin_fmaf(nd.hi[0][s], ivxf, noxf);
+                const float tay = __builtin_fmaf(nd.lo[1][s], ivyf, noyf), tby = __builtin_fmaf(nd.hi[1][s], ivyf, noyf);
+                const float taz = __builtin_fmaf(nd.lo[2][s], ivzf, nozf), tbz = __builtin_fmaf(nd.hi[2][s], ivzf, nozf);
+                // v_min/v_max return the other operand for a NaN: a NaN slab (0 * inf) constrains nothing
+                float nx_ = __builtin_fminf(tax, tbx), ny_ = __builtin_fminf(tay, tby), nz_ = __builtin_fminf(taz, tbz);
+                float fx_ = __builtin_fmaxf(tax, tbx), fy_ = __builtin_fmaxf(tay, tby), fz_ = __builtin_fmaxf(taz, tbz);
+                if (FAR) {
+                    nx_ -= exf; ny_ -= eyf; nz_ -= ezf;
+                    fx_ += exf; fy_ += eyf; fz_ += ezf;
+                }
+                t0[s] = __builtin_fmaxf(__builtin_fmaxf(nx_, ny_), __builtin_fmaxf(nz_, tminf));
+                const float t1 = __builtin_fminf(__builtin_fminf(fx_, fy_), __builtin_fminf(fz_, tmaxf));
+                hb |= (t1 < t0[s]) ? 0u : (1u << s);
             }
-            {
-                const float tax = (nd.lo1[0] - fox) * ivxf, tbx = (nd.hi1[0] - fox) * ivxf;
-                const float tay = (nd.lo1[1] - foy) * ivyf, tby = (nd.hi1[1] - foy) * ivyf;
-                const float taz = (nd.lo1[2] - foz) * ivzf, tbz = (nd.hi1[2] - foz) * ivzf;
-                t0b = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)),
-                                      __builtin_fmaxf(__builtin_fminf(taz, tbz), tminf));
-                const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
-                                                 __builtin_fminf(__builtin_fmaxf(taz, tbz), tmaxf));
-                h1 = !(t1 < t0b);
+            if (!trust) {  // rays outside the analysed range visit everything
+                hb = 0xfu;
+                t0[0] = t0[1] = t0[2] = t0[3] = 0.0f;
             }
-            if (!trust) { h0 = true; h1 = true; t0a = 0; t0b = 0; }  // rays outside the analysed range visit everything
-            if (h0 && h1) {
-                const bool first0 = !(t0b < t0a);  // nearer child first
-                stack[sp * PT_BLOCK] = first0 ? nd.c1 : nd.c0;
-                sp++;
-                cur = first0 ? nd.c0 : nd.c1;
-            } else if (h0) {
-                cur = nd.c0;
-            } else if (h1) {
-                cur = nd.c1;
+            const uint32_t ih = hb & (nd.meta >> 8);   // internal children pierced (bits 4.. are cleared by hb)
+            const uint32_t oh = hb & (nd.meta >> 12);  // object children pierced
+            // internal children nearest first: sort keys = entry parameter (>= 0, so its bits order like the
+            // value) with 2*slot in the low three bits; 0xffffffff = not a candidate
+            uint32_t k0, k1, k2, k3;
+            {
+                uint32_t key[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const uint32_t bits = (__float_as_uint(__builtin_fmaxf(t0[s], 0.0f)) & ~7u) | (uint32_t)(2 * s);
+                    key[s] = (ih & (1u << s)) ? bits : 0xffffffffu;
+                }
+                // 5-exchange network
+                uint32_t a0 = key[0] < key[1] ? key[0] : key[1], a1 = key[0] < key[1] ? key[1] : key[0];
+                uint32_t a2 = key[2] < key[3] ? key[2] : key[3], a3 = key[2] < key[3] ? key[3] : key[2];
+                k0 = a0 < a2 ? a0 : a2;
+                const uint32_t m0 = a0 < a2 ? a2 : a0;
+                k3 = a1 < a3 ? a3 : a1;
+                const uint32_t m1 = a1 < a3 ? a1 : a3;
+                k1 = m0 < m1 ? m0 : m1;
+                k2 = m0 < m1 ? m1 : m0;
+            }
+            const uint32_t meta = nd.meta;
+            const int nbase = nd.node_base;
+#define PT_CHILD(k) (nbase + (int)((meta >> ((k) & 7u)) & 3u))
+            if (k3 != 0xffffffffu) { stack[sp * PT_BLOCK] = PT_CHILD(k3); sp++; }
+            if (k2 != 0xffffffffu) { stack[sp * PT_BLOCK] = PT_CHILD(k2); sp++; }
+            if (k1 != 0xffffffffu) { stack[sp * PT_BLOCK] = PT_CHILD(k1); sp++; }
+            if (k0 != 0xffffffffu) {
+                cur = PT_CHILD(k0);
             } else if (sp > 0) {
                 sp--;
                 cur = stack[sp * PT_BLOCK];
             } else {
-                cur = DONE;
+                cur = -1;
+            }
+#undef PT_CHILD
+            if (oh != 0) {
+                pend = oh;
+                pend_meta = meta;
+                pend_base = nd.obj_base;
+                break;
             }
         }
-        // ---- leaf: exact tests
-        if (cur != DONE) {
+        // ---- exact tests of the objects gathered at the last node
+        if (pend != 0) {
             PH_BEGIN(SEC_NSPH)
             if (PROF) n_leaf++;
-            const uint32_t code = ~(uint32_t)cur;
-            const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                const BvhObj &bo = bobjs[first + k];
+            while (pend != 0) {
+                const uint32_t s = (uint32_t)__builtin_ctz(pend);
+                pend &= pend - 1;
+                const BvhObj &bo = bobjs[pend_base + (int)((pend_meta >> (2u * s)) & 3u)];
                 if (PROF) ph.exec[SEC_NBOX]++;  // exact object tests (lane count)
                 const int kind = bo.o.kind & 0xff;
                 if (mode != 0 && !(bo.o.kind & 0x100)) continue;
@@ -520,12 +569,6 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                     tmaxf = (float)(tmax - ts);
                     tmaxf += __builtin_fabsf(tmaxf) * 4.8e-7f;
                 }
-            }
-            if (sp > 0) {
-                sp--;
-                cur = stack[sp * PT_BLOCK];
-            } else {
-                cur = DONE;
             }
             PH_END(SEC_NSPH)
         }
@@ -792,22 +835,27 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             } else {
                 // The culled strategies assume every candidate t is a number and that the reference's FP64 tests
                 // mean what the geometry says.  Rays with non-finite or absurd components (a 1-pixel-wide frame
-                // divides by W-1 = 0, renderer.go:95) and rays from astronomically far away (clip_ray) break
-                // that: a wave holding one takes the plain sequential scan, which IS the reference's loop.
+                // divides by W-1 = 0, renderer.go:95) break the first; a wave holding one takes the plain sequential
+                // scan, which IS the reference's loop.  Rays from astronomically far away (clip_ray) break the
+                // second: the bitmask strategy treats them the same way, the BVH widens its bounds for them.
                 const double a_ = dx * dx + dy * dy + dz * dz;
                 const Clip clip = clip_ray(F, ray, mode ? 0.0001 : 0.001);
+                constexpr bool BITMASK = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY);
                 const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
-                                  (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100) && !clip.far;
+                                  (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100) && !(BITMASK && clip.far);
                 const bool plain = __ballot(!tame) != 0;
                 constexpr bool VERIFY = (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_BVH);
                 if (plain) {
                     scan_uniform(F, g_obj, ray, mode, best, tmax);
                 } else {
-                    if (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY)
+                    if (BITMASK)
                         scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
+                    else if (__ballot(clip.far) != 0)
+                        scan_bvh<PROF, true>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, clip,
+                                             mode, best, tmax, ph);
                     else
-                        scan_bvh<PROF>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, clip, mode,
-                                       best, tmax, ph);
+                        scan_bvh<PROF, false>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, clip,
+                                              mode, best, tmax, ph);
                     if (VERIFY) {
                         int best2;
                         double tmax2;

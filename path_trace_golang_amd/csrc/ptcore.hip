@@ -142,6 +142,7 @@ struct SceneData {
     std::vector<BvhNode> bvh_nodes;
     std::vector<BvhObj> bvh_objs;
     int bvh_depth = 0;
+    int bvh_stack_need = 0;
     size_t lds_bytes = 0;
     int scan = 0;
     DevFrame Fs{};  // the scene-dependent fields of DevFrame
@@ -725,42 +726,16 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
         const double margin = Bnd * (1.0 / 4096.0);
         ptbvh::Built built = ptbvh::build(w, finite, margin);
         ptbvh::Built builtd = ptbvh::build(w, glass, margin);
-        if (built.depth >= PT_BVH_STACK || builtd.depth >= PT_BVH_STACK)
-            return fail(PT_ERR_INVALID, "BVH deeper than the traversal stack");
-        {
-            // breadth-first node order for the main tree: its top levels become one contiguous packet
-            // that every block stages in LDS (the builder emits depth-first order)
-            const std::vector<BvhNode> &src = built.nodes;
-            std::vector<int32_t> order, where(src.size(), -1);
-            order.reserve(src.size());
-            if (!src.empty()) order.push_back(0);
-            for (size_t q = 0; q < order.size(); q++) {
-                const BvhNode &nd = src[(size_t)order[q]];
-                if (nd.c0 >= 0) order.push_back(nd.c0);
-                if (nd.c1 >= 0) order.push_back(nd.c1);
-            }
-            for (size_t q = 0; q < order.size(); q++) where[(size_t)order[q]] = (int32_t)q;
-            std::vector<BvhNode> bfs(order.size());
-            for (size_t q = 0; q < order.size(); q++) {
-                BvhNode nd = src[(size_t)order[q]];
-                if (nd.c0 >= 0) nd.c0 = where[(size_t)nd.c0];
-                if (nd.c1 >= 0) nd.c1 = where[(size_t)nd.c1];
-                bfs[q] = nd;
-            }
-            built.nodes.swap(bfs);
-        }
         sd.bvh_depth = std::max(built.depth, builtd.depth);
+        sd.bvh_stack_need = std::max(built.stack_need, builtd.stack_need);
+        if (sd.bvh_stack_need >= PT_BVH_STACK)
+            return fail(PT_ERR_INVALID, "BVH deeper than the traversal stack");
         const int32_t node_off = (int32_t)built.nodes.size(), obj_off = (int32_t)built.order.size();
         F.bvh_main_nodes = node_off;
         sd.bvh_nodes = std::move(built.nodes);
-        for (BvhNode nd : builtd.nodes) {  // append, re-basing node indices and leaf ranges
-            auto rebase = [&](int32_t c) -> int32_t {
-                if (c >= 0) return c + node_off;
-                const uint32_t code = ~(uint32_t)c;
-                return ~(int32_t)(((code & 0x0fffffffu) + (uint32_t)obj_off) | (code & 0xf0000000u));
-            };
-            nd.c0 = rebase(nd.c0);
-            nd.c1 = rebase(nd.c1);
+        for (BvhNode nd : builtd.nodes) {  // the dielectric tree follows the main one in both arrays
+            nd.node_base += node_off;
+            nd.obj_base += obj_off;
             sd.bvh_nodes.push_back(nd);
         }
         sd.bvh_objs.resize(built.order.size() + builtd.order.size());
@@ -778,7 +753,7 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     F.world_in_lds = big ? 0 : 1;
     // LDS plan of the BVH path: per-lane stacks sized by the tree depth, and the first (top-level)
     // nodes of the main tree in what is left of a 40 KiB budget (4 blocks of 256 threads per CU)
-    F.bvh_stack = big ? std::max(8, ((sd.bvh_depth + 1 + 3) / 4) * 4) : 0;
+    F.bvh_stack = big ? std::max(4, ((sd.bvh_stack_need + 1 + 3) / 4) * 4) : 0;
     const size_t stack_bytes = (size_t)F.bvh_stack * PT_BLOCK * sizeof(int);
     F.bvh_lds_nodes = 0;
     if (big && F.bvh_root == 0 && stack_bytes < 40960)
@@ -994,8 +969,8 @@ int32_t pt_debug_profile(pt_ctx *ctx, uint64_t *out, int32_t n) {
 }
 
 // Host-only: builds the BVH of `scene` exactly as a render would and checks its invariants.
-// out = {nodes, objects, depth, largest leaf, objects missing or duplicated, objects outside their
-// leaf's box, child boxes not inside the parent's box, plane count}.
+// out = {nodes, objects, depth, most slots used in a node, objects (or nodes) not reached exactly once,
+// objects outside their slot's box, child boxes not inside the parent's box (or malformed slots), plane count}.
 int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]) {
     if (!scene || !out) return fail(PT_ERR_INVALID, "null argument");
     if (scene->num_materials < 0 || scene->num_objects < 0) return fail(PT_ERR_INVALID, "negative scene counts");
@@ -1014,46 +989,53 @@ int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]) {
     const double margin = Bnd * (1.0 / 4096.0);
     ptbvh::Built b = ptbvh::build(world, finite, margin);
     std::vector<int> seen(world.size(), 0);
-    int largest = 0, outside = 0, nested = 0;
-    struct Item { int32_t code; float lo[3], hi[3]; };
+    int widest = 0, outside = 0, nested = 0;
+    struct Item { int32_t node; float lo[3], hi[3]; };
     std::vector<Item> st;
     if (!b.nodes.empty()) {
         Item r;
-        r.code = 0;
+        r.node = 0;
         for (int k = 0; k < 3; k++) { r.lo[k] = -INFINITY; r.hi[k] = INFINITY; }
         st.push_back(r);
     }
+    std::vector<int> visits(b.nodes.size(), 0);
     while (!st.empty()) {
-        Item it = st.back();
+        const Item it = st.back();
         st.pop_back();
-        if (it.code >= 0) {
-            const BvhNode &nd = b.nodes[(size_t)it.code];
-            Item c0, c1;
-            c0.code = nd.c0; c1.code = nd.c1;
-            for (int k = 0; k < 3; k++) {
-                c0.lo[k] = nd.lo0[k]; c0.hi[k] = nd.hi0[k]; c1.lo[k] = nd.lo1[k]; c1.hi[k] = nd.hi1[k];
-                if (nd.lo0[k] < it.lo[k] || nd.hi0[k] > it.hi[k] || nd.lo1[k] < it.lo[k] || nd.hi1[k] > it.hi[k]) nested++;
-            }
-            st.push_back(c0);
-            st.push_back(c1);
-        } else {
-            const uint32_t code = ~(uint32_t)it.code;
-            const uint32_t first = code & 0x0fffffffu, count = (code >> 28) + 1u;
-            largest = std::max(largest, (int)count);
-            for (uint32_t k = 0; k < count; k++) {
-                const int32_t oi = b.order[first + k];
+        const BvhNode &nd = b.nodes[(size_t)it.node];
+        visits[(size_t)it.node]++;
+        const uint32_t intm = (nd.meta >> 8) & 0xfu, objm = (nd.meta >> 12) & 0xfu;
+        if (intm & objm) nested++;  // a slot is one or the other
+        widest = std::max(widest, __builtin_popcount(intm | objm));
+        for (int s = 0; s < 4; s++) {
+            if (!((intm | objm) & (1u << s))) continue;
+            const int rank = (int)((nd.meta >> (2 * s)) & 3u);
+            for (int k = 0; k < 3; k++)
+                if (nd.lo[k][s] < it.lo[k] || nd.hi[k][s] > it.hi[k]) nested++;
+            if (intm & (1u << s)) {
+                Item c;
+                c.node = nd.node_base + rank;
+                for (int k = 0; k < 3; k++) { c.lo[k] = nd.lo[k][s]; c.hi[k] = nd.hi[k][s]; }
+                if (c.node <= it.node || c.node >= (int32_t)b.nodes.size()) { nested++; continue; }
+                st.push_back(c);
+            } else {
+                const int32_t slot = nd.obj_base + rank;
+                if (slot < 0 || slot >= (int32_t)b.order.size()) { outside++; continue; }
+                const int32_t oi = b.order[(size_t)slot];
                 seen[(size_t)oi]++;
                 const ptbvh::Aabb bb = ptbvh::object_bounds(world[(size_t)oi]);
                 for (int a = 0; a < 3; a++)
-                    if ((double)it.lo[a] > bb.lo[a] - margin * 0.999 || (double)it.hi[a] < bb.hi[a] + margin * 0.999) { outside++; break; }
+                    if ((double)nd.lo[a][s] > bb.lo[a] - margin * 0.999 || (double)nd.hi[a][s] < bb.hi[a] + margin * 0.999) { outside++; break; }
             }
         }
     }
     int bad = 0;
-    for (int32_t i : finite) {
-        // a scene of one object lists its leaf twice on purpose
-        if (seen[(size_t)i] < 1 || (seen[(size_t)i] > 1 && finite.size() > 1)) bad++;
-    }
+    for (int32_t i : finite)
+        if (seen[(size_t)i] != 1) bad++;
+    for (int v : visits)
+        if (v != 1) bad++;
+    const int largest = widest;
+    if (b.stack_need >= PT_BVH_STACK) bad++;
     out[0] = (int32_t)b.nodes.size();
     out[1] = (int32_t)b.order.size();
     out[2] = b.depth;

@@ -48,3 +48,31 @@ def test_large_scene_renders_and_is_device_count_invariant():
             assert st["samples"] == w * h * spp and np.all(np.isfinite(acc)) and np.all(img[..., 3] == 255)
             outs.append((img, acc, st["segments"]))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
+@pytest.mark.parametrize("cam_scale", [3.0e3, 3.0e5, 1.0e8, 1.0e11])
+def test_far_cameras_through_the_bvh(gpu_ctx, oracle, cam_scale):
+    # Seen from thousands of scene sizes away the reference's FP64 sphere discriminant cancels and reports
+    # hits the geometry does not have; the BVH widens its bounds per ray so that those survive (clip_ray).
+    from path_trace_golang_amd import capi, hip, scene, synth
+
+    sc = synth.make_scene(150, 11)
+    doc = sc.encode()
+    cam = doc["camera"]
+    t = cam["target"]
+    cam["position"] = {"x": t["x"] + 0.3 * cam_scale, "y": t["y"] + 0.5 * cam_scale, "z": t["z"] + cam_scale}
+    cam["fov"] = 1500.0 / cam_scale  # the scene (about 30 units across) fills the frame
+    cam["aperture"] = 0
+    cam["focus_dist"] = 0
+    sc = scene.Scene.decode(doc)
+    w, h, spp, depth, seed = 64, 48, 3, 6, 5
+    o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=seed)
+    img = np.zeros((h, w, 4), np.uint8)
+    nseg = np.zeros((h, w), np.uint32)
+    ndraw = np.zeros((h, w), np.uint32)
+    st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, None, nseg, ndraw,
+                    ctx=gpu_ctx)
+    assert o["stats"]["segments"] > w * h * spp  # the camera does see the scene
+    assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"]
+    assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
+    assert np.array_equal(img, o["rgba"])
