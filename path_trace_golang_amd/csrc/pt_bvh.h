@@ -259,7 +259,7 @@ inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> 
                 ni++;
             }
         }
-        nd.meta = ranks | (intm << 8) | (objm << 12);
+        nd.meta = ranks | (intm << 8) | (objm << 12) | ((~intm & 0xfu) << 16);
         out.nodes.push_back(nd);
         out.depth = std::max(out.depth, level[q]);
     }

@@ -70,7 +70,7 @@ static_assert(sizeof(BroadBox) == 32, "BroadBox layout");
 // brings the same bound of all four.  Nodes are numbered breadth-first: the internal children of a
 // node are node_base + rank, its object children bvh_objs[obj_base + rank].
 //   meta bits 0-7: rank of slot s within its kind at bits [2s, 2s+2); 8-11: slot is an internal node;
-//   12-15: slot is an object.
+//   12-15: slot is an object; 16-19: slot is NOT an internal node (complement of 8-11).
 struct alignas(16) BvhNode {
     float lo[3][4];   // [axis][slot]
     float hi[3][4];

@@ -405,11 +405,21 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     }
 }
 
+// True when the FP32 quantities scan_bvh derives from the ray are inside the range its bounds were analysed
+// for (direction length and re-based origin); a little stricter than the FP32 test of the careful
+// instantiation, so a wave that passes here needs no per-node check.
+__device__ __forceinline__ bool bvh_ray_trusted(const DevFrame &F, const RayD &r, const Clip &clip, double a) {
+    const double lim = 0.99 * (double)F.origin_bound;
+    return (a > 1e-29) && (a < 1e29) && (ptm::f_abs(r.ox + r.dx * clip.ts) <= lim) &&
+           (ptm::f_abs(r.oy + r.dy * clip.ts) <= lim) && (ptm::f_abs(r.oz + r.dz * clip.ts) <= lim);
+}
+
 // Closest hit / exit search through the BVH.  Traversal order and culling only decide which
 // objects get the exact test; `wins` makes the result independent of that order.
-// FAR: some lane of the wave carries clip.infl > 0 (see clip_ray); every node and object bound is then
-// widened by the lane's own infl.
-template <bool PROF, bool FAR, typename ObjPtr, typename IdxPtr>
+// CAREFUL: some lane of the wave carries clip.infl > 0 (see clip_ray; every node and object bound is then
+// widened by the lane's own infl) or a ray the FP32 bounds were not analysed for (it visits every node).
+// The caller guarantees bvh_ray_trusted() for every lane of a wave it sends to the other instantiation.
+template <bool PROF, bool CAREFUL, typename ObjPtr, typename IdxPtr>
 __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr g_pl, const BvhNode *__restrict__ nodes,
                                          const BvhNode *lds_nodes /* nodes[0 .. F.bvh_lds_nodes) staged in LDS */,
                                          const BvhObj *__restrict__ bobjs, int *stack /* this lane's column, stride PT_BLOCK */,
@@ -447,17 +457,20 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     const float fox = (float)(r.ox + r.dx * ts), foy = (float)(r.oy + r.dy * ts), foz = (float)(r.oz + r.dz * ts);
     const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
     const float fa = __builtin_fmaf(fdx, fdx, __builtin_fmaf(fdy, fdy, fdz * fdz));
-    const bool trust = (fa > 1e-30f) && (fa < 1e30f) && (__builtin_fabsf(fox) <= F.origin_bound) &&
-                       (__builtin_fabsf(foy) <= F.origin_bound) && (__builtin_fabsf(foz) <= F.origin_bound);
+    const bool trust = !CAREFUL || ((fa > 1e-30f) && (fa < 1e30f) && (__builtin_fabsf(fox) <= F.origin_bound) &&
+                                    (__builtin_fabsf(foy) <= F.origin_bound) && (__builtin_fabsf(foz) <= F.origin_bound));
     // node parameters are relative to the re-based origin: t' = t - ts
     float tminf = (float)((mode ? 0.0001 : 0.001) - ts);
     tminf -= __builtin_fabsf(tminf) * 1e-2f + 1e-6f;  // a little below tMin - ts
+    // A re-based ray starts on the scene cube, which keeps B/512 - m of clearance around every bound: nothing
+    // begins before t' = 0.  With that every entry parameter below is >= 0 and its bit pattern orders like it.
+    tminf = __builtin_fmaxf(tminf, 0.0f);
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
     // slab parameters as bound * (1/d) - o/d (see scan_broad_narrow)
     const float noxf = -fox * ivxf, noyf = -foy * ivyf, nozf = -foz * ivzf;
     // widening of a slab by infl in parameter units (a little more than infl / |d|; inf or NaN for a zero
     // component, which unconstrains the slab)
-    const float inflf = FAR ? (float)clip.infl * 1.0001f : 0.0f;
+    const float inflf = CAREFUL ? (float)clip.infl * 1.0001f : 0.0f;
     const float exf = inflf * __builtin_fabsf(ivxf), eyf = inflf * __builtin_fabsf(ivyf), ezf = inflf * __builtin_fabsf(ivzf);
     float tmaxf = (float)(tmax - ts);
     tmaxf += __builtin_fabsf(tmaxf) * 4.8e-7f;  // >= tmax - ts (MaxFloat64 becomes +inf)
@@ -485,7 +498,7 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 // v_min/v_max return the other operand for a NaN: a NaN slab (0 * inf) constrains nothing
                 float nx_ = __builtin_fminf(tax, tbx), ny_ = __builtin_fminf(tay, tby), nz_ = __builtin_fminf(taz, tbz);
                 float fx_ = __builtin_fmaxf(tax, tbx), fy_ = __builtin_fmaxf(tay, tby), fz_ = __builtin_fmaxf(taz, tbz);
-                if (FAR) {
+                if (CAREFUL) {
                     nx_ -= exf; ny_ -= eyf; nz_ -= ezf;
                     fx_ += exf; fy_ += eyf; fz_ += ezf;
                 }
@@ -493,12 +506,12 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 const float t1 = __builtin_fminf(__builtin_fminf(fx_, fy_), __builtin_fminf(fz_, tmaxf));
                 hb |= (t1 < t0[s]) ? 0u : (1u << s);
             }
-            if (!trust) {  // rays outside the analysed range visit everything
+            if (CAREFUL && !trust) {  // rays outside the analysed range visit everything
                 hb = 0xfu;
                 t0[0] = t0[1] = t0[2] = t0[3] = 0.0f;
             }
-            const uint32_t ih = hb & (nd.meta >> 8);   // internal children pierced (bits 4.. are cleared by hb)
-            const uint32_t oh = hb & (nd.meta >> 12);  // object children pierced
+            const uint32_t meta = nd.meta;
+            const uint32_t oh = hb & (meta >> 12);  // object children pierced (hb has only bits 0-3)
             // internal children nearest first: sort keys = entry parameter (>= 0, so its bits order like the
             // value) with 2*slot in the low three bits; 0xffffffff = not a candidate
             uint32_t k0, k1, k2, k3;
@@ -506,8 +519,10 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 uint32_t key[4];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    const uint32_t bits = (__float_as_uint(__builtin_fmaxf(t0[s], 0.0f)) & ~7u) | (uint32_t)(2 * s);
-                    key[s] = (ih & (1u << s)) ? bits : 0xffffffffu;
+                    const uint32_t bits = (__float_as_uint(t0[s]) & ~7u) | (uint32_t)(2 * s);
+                    // sign-extended one-bit field: all ones when slot s is NOT an internal node (meta bits 16-19)
+                    const uint32_t not_internal = (uint32_t)__builtin_amdgcn_sbfe((int)meta, 16 + s, 1);
+                    key[s] = ((hb & (1u << s)) ? bits : 0xffffffffu) | not_internal;
                 }
                 // 5-exchange network
                 uint32_t a0 = key[0] < key[1] ? key[0] : key[1], a1 = key[0] < key[1] ? key[1] : key[0];
@@ -519,12 +534,17 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 k1 = m0 < m1 ? m0 : m1;
                 k2 = m0 < m1 ? m1 : m0;
             }
-            const uint32_t meta = nd.meta;
             const int nbase = nd.node_base;
 #define PT_CHILD(k) (nbase + (int)((meta >> ((k) & 7u)) & 3u))
-            if (k3 != 0xffffffffu) { stack[sp * PT_BLOCK] = PT_CHILD(k3); sp++; }
-            if (k2 != 0xffffffffu) { stack[sp * PT_BLOCK] = PT_CHILD(k2); sp++; }
-            if (k1 != 0xffffffffu) { stack[sp * PT_BLOCK] = PT_CHILD(k1); sp++; }
+            if (k1 != 0xffffffffu) {  // sorted: k2 and k3 can only be candidates when k1 is
+                if (k2 != 0xffffffffu) {
+                    if (k3 != 0xffffffffu) { stack[sp * PT_BLOCK] = PT_CHILD(k3); sp++; }
+                    stack[sp * PT_BLOCK] = PT_CHILD(k2);
+                    sp++;
+                }
+                stack[sp * PT_BLOCK] = PT_CHILD(k1);
+                sp++;
+            }
             if (k0 != 0xffffffffu) {
                 cur = PT_CHILD(k0);
             } else if (sp > 0) {
@@ -850,7 +870,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 } else {
                     if (BITMASK)
                         scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
-                    else if (__ballot(clip.far) != 0)
+                    else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
                         scan_bvh<PROF, true>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, clip,
                                              mode, best, tmax, ph);
                     else
