@@ -243,7 +243,9 @@ __device__ __forceinline__ Clip clip_ray(const DevFrame &F, const RayD &r, doubl
     Clip c{0.0, 0.0, 0.0, false, false};
     double Bs = F.scene_bound;
     if (!(ptm::f_abs(r.ox) <= Bs && ptm::f_abs(r.oy) <= Bs && ptm::f_abs(r.oz) <= Bs)) {
-        const double ix = 1 / r.dx, iy = 1 / r.dy, iz = 1 / r.dz;
+        // v_rcp_f64 (relative error < 2^-26) instead of three IEEE divisions: the entry point may be off by
+        // ~1.5e-8 * reach <= 3e-5 B, and the cube keeps B/512 - m = 1.7e-3 B of clearance around every bound
+        const double ix = __builtin_amdgcn_rcp(r.dx), iy = __builtin_amdgcn_rcp(r.dy), iz = __builtin_amdgcn_rcp(r.dz);
         double te, tx;
         auto cube = [&]() {
             const double x0 = (-Bs - r.ox) * ix, x1 = (Bs - r.ox) * ix;

@@ -118,7 +118,7 @@ def _ptr(a: Optional[np.ndarray]):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def render(sc: scn.Scene, cfg: RenderConfig, img: np.ndarray, progress: Optional[Callable[[], None]] = None,
+def render(sc, cfg: RenderConfig, img: np.ndarray, progress: Optional[Callable[[], None]] = None,
            accum: Optional[np.ndarray] = None, nseg: Optional[np.ndarray] = None,
            ndraw: Optional[np.ndarray] = None, ctx: Optional[capi.Context] = None) -> dict:
     """Fills img (uint8 [H, W, 4], C-contiguous rows; row stride may exceed 4*W).
@@ -136,7 +136,7 @@ def render(sc: scn.Scene, cfg: RenderConfig, img: np.ndarray, progress: Optional
         return {}
     if img.strides[2] != 1 or img.strides[1] != 4:
         raise ValueError("img rows must be contiguous RGBA")
-    flat = FlatScene(sc)
+    flat = sc if isinstance(sc, FlatScene) else FlatScene(sc)  # callers that render one scene repeatedly flatten it once
     pc = pt_config(cfg)
     st = capi.PtStats()
     if accum is not None and (accum.dtype != np.float64 or accum.shape != (cfg.height, cfg.width, 3)

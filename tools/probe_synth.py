@@ -9,7 +9,7 @@ L = capi.load()
 ns = [int(a) for a in sys.argv[1:]] or [1000, 10000, 100000, 1000000]
 w, h, spp, d = 1920, 1080, 16, 8
 for n in ns:
-    t = time.time(); sc = synth.make_scene(n, 1); tg = time.time() - t
+    t = time.time(); sc = hip.FlatScene(synth.make_scene(n, 1)); tg = time.time() - t
     img = np.zeros((h, w, 4), np.uint8)
     cfg = hip.RenderConfig(w, h, spp, d, 1)
     t = time.time(); st = hip.render(sc, cfg, img, ctx=ctx); t1 = time.time() - t
