@@ -174,6 +174,13 @@ def main() -> int:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+    # per-rank device-busy time of the render (imbalance) next to the whole step (render + tile gather + untile)
+    busy = torch.tensor([sum(s.device_ms for s in stats) / max(1, args.steps)], dtype=torch.float64, device=red_dev)
+    busy_all = [busy]
+    if world > 1:
+        busy_all = [torch.zeros_like(busy) for _ in range(world)]
+        dist.all_gather(busy_all, busy)
+    busy_ms = [float(b.item()) for b in busy_all]
     segments, samples, exits = (float(x) for x in tot.tolist())
 
     out = None
@@ -226,6 +233,8 @@ def main() -> int:
                                    % (args.scene, W, H, args.spp, args.depth, args.seed),
                        "tiles": "32x32 interleaved over %d rank(s)" % world, "gather": ("rccl" if backend == "nccl" else backend + " (rehearsal)") if world > 1 else "none",
                        "spp_chunk": chunk},
+            "per_rank_render_ms_per_step": busy_ms,
+            "gather_untile_host_ms_per_step": elapsed / steps * 1e3 - max(busy_ms),
             "primary_msamples_per_s": samples / elapsed / 1e6,
             "segments_per_sample": segments / max(samples, 1.0),
             "exit_scans_per_segment": exits / max(segments, 1.0),
