@@ -2,8 +2,7 @@
 //
 //   trace_kernel    persistent waves; every lane owns one path at a time and pulls the
 //                   next (pixel, sample) job from a wave-level cursor that is refilled
-//                   from one global queue (ballot + mbcnt prefix rank).  Ray generation
-//                   (camera.go:60-74, renderer.go:181-184), the closest-hit scan over the
+//                   from one global queue (ballot + mbcnt prefix rank).  The closest-hit scan over the
 //                   world (renderer.go:297-302; objects.go:37-222), shading
 //                   (materials.go:74-224), the dielectric exit search (renderer.go:316-371)
 //                   and Russian roulette (renderer.go:375-393) run in one loop whose
@@ -16,11 +15,14 @@
 //                                   builds a per-lane candidate bitmask, then each lane runs
 //                                   the exact FP64 tests only on its own candidates (per-lane
 //                                   look-ups in the LDS copy of the world).  Needs <= 32 spheres and <= 32 boxes.
-//                     SCAN_BVH      larger scenes: per-lane traversal of a binary BVH whose
-//                                   FP32 node boxes are conservative (same inflation as the broad
-//                                   phase), exact FP64 tests at the leaves; nodes and objects are
-//                                   read from HBM/L2, the traversal stack lives in LDS.
+//                     SCAN_BVH      larger scenes: per-lane traversal of a 4-wide BVH whose FP32
+//                                   slot boxes are conservative (same inflation as the broad phase);
+//                                   a slot is an internal node or one object, the exact FP64 test
+//                                   runs on the objects whose own box is pierced; nodes and objects
+//                                   are read from HBM/L2 (top of the tree from LDS), the stack is in LDS.
 //                     SCAN_VERIFY*  run a culled strategy AND the plain scan, count disagreements.
+//   raygen_kernel   one thread per job: stream init, pixel jitter and camera.getRay
+//                   (camera.go:60-74, renderer.go:181-184) as a coherent pre-pass of every chunk.
 //   resolve_kernel  per pixel slot, adds the chunk's sample radiances IN SAMPLE ORDER
 //                   to the running sum (renderer.go:186), and on request finishes the
 //                   pixel: 1/spp, sqrt gamma, *255.999, clamp, truncate (renderer.go:190-221).
@@ -597,7 +599,7 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     }
     PH_END(SEC_BROAD)
     if (PROF) {
-        // histogram of leaves visited per scan: bins <4, <16, <64, <256, <1024, >=1024 (closest-hit scans in
+        // histogram of object batches per scan: bins <4, <16, <64, <256, <1024, >=1024 (closest-hit scans in
         // the `exec` counters of three otherwise unused section ids and their `cyc` words, exit searches in `lanes`)
         const int bin = n_leaf < 4 ? 0 : n_leaf < 16 ? 1 : n_leaf < 64 ? 2 : n_leaf < 256 ? 3 : n_leaf < 1024 ? 4 : 5;
         if (bin == 5 && ph.dbg) {  // sample one very long traversal

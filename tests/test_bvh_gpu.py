@@ -1,4 +1,4 @@
-"""Scenes with more than 64 objects take the BVH path.  The hierarchy only decides
+"""Scenes with more than 32 spheres or 32 boxes take the BVH path.  The hierarchy only decides
 which objects get the exact FP64 test, so the result must equal the reference's linear scan (the oracle)
 exactly: same per-pixel segment/draw counts, same 8-bit image."""
 import numpy as np

@@ -85,8 +85,9 @@ def test_shard_tile_counts_agree_with_python_tiling():
 
 
 def test_bvh_builder_invariants_on_cpu():
-    # host-only: the hierarchy used beyond 64 objects keeps every finite object in exactly one leaf, inside
-    # its leaf box, with nested boxes, leaves of at most four and a depth within the traversal stack
+    # host-only: the 4-wide hierarchy used beyond the candidate bitmasks reaches every finite object and every
+    # node exactly once, keeps each object inside its slot's box, nests child boxes in their parent's, uses at
+    # most four slots per node and needs a traversal stack within the kernel's limit
     import ctypes as C
 
     from conftest import SCENE_NAMES, scene_path
@@ -98,11 +99,11 @@ def test_bvh_builder_invariants_on_cpu():
         flat = hip.FlatScene(sc)
         out = (C.c_int32 * 8)()
         assert lib.pt_debug_bvh_check(C.byref(flat.c), out) == 0
-        nodes, objs, depth, leaf, bad, outside, nested, planes = list(out)
+        nodes, objs, depth, slots, bad, outside, nested, planes = list(out)
         finite = sum(1 for o in sc.objects if o.type in ("sphere", "sphere_light", "box"))
         assert objs == finite and planes == sum(1 for o in sc.objects if o.type == "plane")
         assert bad == 0 and outside == 0 and nested == 0
-        assert leaf <= 4 and depth < 48 and nodes >= 1
+        assert slots <= 4 and depth < 48 and nodes >= 1
 
 
 def test_synthetic_scene_is_reproducible_and_in_schema(tmp_path):

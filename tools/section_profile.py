@@ -29,7 +29,7 @@ for i, s in enumerate(SEC):
 
 if name.startswith("synth:"):
     g = lambda i, k: buf[3 * SEC.index(i) + k]
-    print("leaves visited per closest-hit scan: <4: %d  <16: %d  <64: %d  <256: %d  <1024: %d  >=1024: %d" % (
+    print("object batches per closest-hit scan: <4: %d  <16: %d  <64: %d  <256: %d  <1024: %d  >=1024: %d" % (
         g("lens", 0), g("lens", 2), g("sph_root", 0), g("sph_root", 2), g("sph_root2", 0), g("sph_root2", 2)))
     print("exit searches (even bins only): <4: %d  [16,64): %d  [256,1024): %d" % (g("lens", 1), g("sph_root", 1), g("sph_root2", 1)))
 
