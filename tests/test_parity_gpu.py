@@ -285,3 +285,38 @@ def test_full_size_properties_c2(gpu_ctx):
     acc_half = np.zeros((h, w, 3))
     hip.render(sc, hip.RenderConfig(w, h, 128, depth, 1), np.zeros((h, w, 4), np.uint8), None, acc_half, ctx=gpu_ctx)
     assert np.all(acc_half <= acc + 1e-9)
+
+
+def test_full_size_c4_windows_match_oracle(gpu_ctx, oracle):
+    # BASELINE config 4 at FULL size (gpu_showcase 1920x1080, 1024 spp, depth 8): the oracle renders windows of
+    # that very frame (same streams: they are keyed by pixel and sample), which must match the GPU frame exactly;
+    # plus size-independent properties of the whole frame.
+    from path_trace_golang_amd import capi, hip, scene
+
+    sc = scene.load(scene_path("gpu_showcase"))
+    w, h, spp, depth, seed = 1920, 1080, 1024, 8, 1
+    img = np.zeros((h, w, 4), np.uint8)
+    acc = np.zeros((h, w, 3))
+    nseg = np.zeros((h, w), np.uint32)
+    ndraw = np.zeros((h, w), np.uint32)
+    st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg, ndraw,
+                    ctx=gpu_ctx)
+    assert st["samples"] == w * h * spp
+    assert int(nseg.sum(dtype=np.uint64)) == st["segments"] and int(ndraw.sum(dtype=np.uint64)) == st["draws"]
+    assert np.all(img[..., 3] == 255) and np.all(np.isfinite(acc)) and np.all(acc >= 0)
+    q = np.clip(np.sqrt(acc * (1.0 / spp)) * 255.999, 0, 255.999).astype(np.uint8)
+    assert np.array_equal(q, img[..., :3])
+    osc = oracle.Scene.load(scene_path("gpu_showcase"))
+    # glass + metal in the middle, the last (24-pixel) tile row with the frame corner, the top-left corner
+    for x0, y0, x1, y1 in [(944, 520, 976, 536), (1900, 1064, 1920, 1080), (0, 0, 16, 8)]:
+        o = oracle.render(osc, w, h, spp, depth, seed=seed, window=(x0, y0, x1, y1))
+        sl = (slice(y0, y1), slice(x0, x1))
+        assert np.array_equal(nseg[sl], o["nseg"][sl]) and np.array_equal(ndraw[sl], o["ndraw"][sl])
+        assert np.array_equal(img[sl], o["rgba"][sl])
+        rel = np.abs(acc[sl] - o["accum"][sl]) / np.maximum(np.abs(o["accum"][sl]), 1e-300)
+        assert rel.max() <= 4 * depth * 2.0 ** -52
+    # the default chunking (91 spp per pass here) against one forced to 64: same pixels
+    img2 = np.zeros((h, w, 4), np.uint8)
+    acc2 = np.zeros((h, w, 3))
+    hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 64), img2, None, acc2, ctx=gpu_ctx)
+    assert np.array_equal(acc, acc2) and np.array_equal(img, img2)
