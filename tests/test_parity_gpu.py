@@ -287,14 +287,21 @@ def test_full_size_properties_c2(gpu_ctx):
     assert np.all(acc_half <= acc + 1e-9)
 
 
-def test_full_size_c4_windows_match_oracle(gpu_ctx, oracle):
-    # BASELINE config 4 at FULL size (gpu_showcase 1920x1080, 1024 spp, depth 8): the oracle renders windows of
-    # that very frame (same streams: they are keyed by pixel and sample), which must match the GPU frame exactly;
-    # plus size-independent properties of the whole frame.
+FULL_SIZE = [  # BASELINE configs 3, 4, 5 at FULL size, with windows of the frame for the oracle
+    ("metal_glass_room", 1920, 1080, 1024, 12, [(930, 560, 962, 576), (1900, 1064, 1920, 1080)]),
+    ("gpu_showcase", 1920, 1080, 1024, 8, [(944, 520, 976, 536), (1900, 1064, 1920, 1080), (0, 0, 16, 8)]),
+    ("test_comprehensive", 3840, 2160, 4096, 16, [(1900, 1100, 1916, 1108), (3824, 2152, 3840, 2160)]),
+]
+
+
+@pytest.mark.parametrize("name,w,h,spp,depth,windows", FULL_SIZE, ids=["C3", "C4", "C5"])
+def test_full_size_windows_match_oracle(gpu_ctx, oracle, name, w, h, spp, depth, windows):
+    # The oracle renders windows of the very frame the configuration names (same streams: they are keyed by
+    # pixel and sample), which must match the GPU frame exactly; plus size-independent properties of the frame.
     from path_trace_golang_amd import capi, hip, scene
 
-    sc = scene.load(scene_path("gpu_showcase"))
-    w, h, spp, depth, seed = 1920, 1080, 1024, 8, 1
+    sc = scene.load(scene_path(name))
+    seed = 1
     img = np.zeros((h, w, 4), np.uint8)
     acc = np.zeros((h, w, 3))
     nseg = np.zeros((h, w), np.uint32)
@@ -306,17 +313,17 @@ def test_full_size_c4_windows_match_oracle(gpu_ctx, oracle):
     assert np.all(img[..., 3] == 255) and np.all(np.isfinite(acc)) and np.all(acc >= 0)
     q = np.clip(np.sqrt(acc * (1.0 / spp)) * 255.999, 0, 255.999).astype(np.uint8)
     assert np.array_equal(q, img[..., :3])
-    osc = oracle.Scene.load(scene_path("gpu_showcase"))
-    # glass + metal in the middle, the last (24-pixel) tile row with the frame corner, the top-left corner
-    for x0, y0, x1, y1 in [(944, 520, 976, 536), (1900, 1064, 1920, 1080), (0, 0, 16, 8)]:
+    osc = oracle.Scene.load(scene_path(name))
+    for x0, y0, x1, y1 in windows:
         o = oracle.render(osc, w, h, spp, depth, seed=seed, window=(x0, y0, x1, y1))
         sl = (slice(y0, y1), slice(x0, x1))
         assert np.array_equal(nseg[sl], o["nseg"][sl]) and np.array_equal(ndraw[sl], o["ndraw"][sl])
         assert np.array_equal(img[sl], o["rgba"][sl])
         rel = np.abs(acc[sl] - o["accum"][sl]) / np.maximum(np.abs(o["accum"][sl]), 1e-300)
         assert rel.max() <= 4 * depth * 2.0 ** -52
-    # the default chunking (91 spp per pass here) against one forced to 64: same pixels
-    img2 = np.zeros((h, w, 4), np.uint8)
-    acc2 = np.zeros((h, w, 3))
-    hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 64), img2, None, acc2, ctx=gpu_ctx)
-    assert np.array_equal(acc, acc2) and np.array_equal(img, img2)
+    if name == "gpu_showcase":
+        # the default chunking (91 spp per pass here) against one forced to 64: same pixels
+        img2 = np.zeros((h, w, 4), np.uint8)
+        acc2 = np.zeros((h, w, 3))
+        hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 64), img2, None, acc2, ctx=gpu_ctx)
+        assert np.array_equal(acc, acc2) and np.array_equal(img, img2)
