@@ -94,7 +94,8 @@ __device__ __forceinline__ void reflect_vec(double vx, double vy, double vz, dou
 // Section ids of the diagnostic build (PROF = true): per section the kernel counts wave
 // executions, active lanes and shader-clock cycles (leader lane only).  The shipping
 // instantiations have PROF = false and contain none of this.
-enum { SEC_ITER = 0, SEC_RAYGEN, SEC_LENS, SEC_SCAN, SEC_SPH_ROOT, SEC_SPH_ROOT2, SEC_HITREC, SEC_COSINE,
+enum { SEC_ITER = 0, SEC_RAYGEN /* loading the pre-generated ray */, SEC_HIST0 /* BVH histogram words */, SEC_SCAN, SEC_HIST1, SEC_HIST2,
+       SEC_HITREC, SEC_COSINE,
        SEC_DIEL, SEC_EXITPOST, SEC_RR, SEC_FINISH, SEC_SKY, SEC_UNITDIR, SEC_BROAD, SEC_NSPH, SEC_NBOX, SEC_PLANE, SEC_COUNT };
 
 
@@ -611,7 +612,7 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
             ph.dbg[4] = ptm::to_bits(r.ox); ph.dbg[5] = ptm::to_bits(r.oy); ph.dbg[6] = ptm::to_bits(r.oz);
             ph.dbg[7] = ptm::to_bits(r.dx); ph.dbg[8] = ptm::to_bits(r.dy); ph.dbg[9] = ptm::to_bits(r.dz);
         }
-        const int id = bin < 2 ? SEC_LENS : bin < 4 ? SEC_SPH_ROOT : SEC_SPH_ROOT2;
+        const int id = bin < 2 ? SEC_HIST0 : bin < 4 ? SEC_HIST1 : SEC_HIST2;
         if (mode == 0) {
             if (bin & 1) ph.cyc[id]++;
             else ph.exec[id]++;

@@ -8,7 +8,7 @@ import numpy as np
 from path_trace_golang_amd import capi, hip, scene
 name = sys.argv[1] if len(sys.argv) > 1 else "gpu_showcase"
 w, h, spp, d = (int(x) for x in (sys.argv[2:6] if len(sys.argv) >= 6 else (1920, 1080, 42, 8)))
-SEC = ["iter", "raygen", "lens", "scan", "sph_root", "sph_root2", "hitrec", "cosine", "diel", "exitpost", "rr",
+SEC = ["iter", "raygen", "hist0", "scan", "hist1", "hist2", "hitrec", "cosine", "diel", "exitpost", "rr",
        "finish", "sky", "unitdir", "broad", "nar_sph", "nar_box", "plane"]
 ctx = capi.Context(ndev=1)
 if name.startswith("synth:"):
@@ -30,8 +30,8 @@ for i, s in enumerate(SEC):
 if name.startswith("synth:"):
     g = lambda i, k: buf[3 * SEC.index(i) + k]
     print("object batches per closest-hit scan: <4: %d  <16: %d  <64: %d  <256: %d  <1024: %d  >=1024: %d" % (
-        g("lens", 0), g("lens", 2), g("sph_root", 0), g("sph_root", 2), g("sph_root2", 0), g("sph_root2", 2)))
-    print("exit searches (even bins only): <4: %d  [16,64): %d  [256,1024): %d" % (g("lens", 1), g("sph_root", 1), g("sph_root2", 1)))
+        g("hist0", 0), g("hist0", 2), g("hist1", 0), g("hist1", 2), g("hist2", 0), g("hist2", 2)))
+    print("exit searches (even bins only): <4: %d  [16,64): %d  [256,1024): %d" % (g("hist0", 1), g("hist1", 1), g("hist2", 1)))
 
 os.environ["PTCORE_VERBOSE"] = "1"
 capi.load().pt_debug_scan_mismatches(ctx.handle)
