@@ -842,7 +842,13 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     SEC_END(SEC_RAYGEN)
                 }
             }
-            if (__ballot(active) == 0) break;  // queue drained and every lane idle
+            if (__ballot(active) == 0) {
+                if (exhausted) break;  // queue drained and every lane idle
+                // every job taken so far lay outside the frame (edge tiles: up to 256*S such jobs in a row):
+                // the queue still holds work, go round again.  (Leaving here instead lost the last tiles of a
+                // frame once more such claims than resident waves piled up at the end of the queue.)
+                continue;
+            }
         }
 
         bool finished = false;

@@ -484,14 +484,22 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         HIP_TRY(d.acc_seg.reserve(ns));
         HIP_TRY(d.acc_draw.reserve(ns));
     }
-    const size_t njobs_max = (size_t)ns * fr.chunk;
-    HIP_TRY(d.L.reserve(4 * njobs_max));
-    HIP_TRY(d.ray.reserve(6 * njobs_max));
-    HIP_TRY(d.ray_rng.reserve(njobs_max));
-    HIP_TRY(d.ray_ndraw.reserve(njobs_max));
-    if (fr.stats_on) {
-        HIP_TRY(d.job_seg.reserve(njobs_max));
-        HIP_TRY(d.job_draw.reserve(njobs_max));
+    // per-chunk job buffers; when the device cannot give that much right now the chunk is halved until it can
+    // (the ordered accumulation makes the pixels independent of the chunk size)
+    for (;;) {
+        const size_t njobs_max = (size_t)ns * fr.chunk;
+        hipError_t e = d.L.reserve(4 * njobs_max);
+        if (e == hipSuccess) e = d.ray.reserve(6 * njobs_max);
+        if (e == hipSuccess) e = d.ray_rng.reserve(njobs_max);
+        if (e == hipSuccess) e = d.ray_ndraw.reserve(njobs_max);
+        if (e == hipSuccess && fr.stats_on) e = d.job_seg.reserve(njobs_max);
+        if (e == hipSuccess && fr.stats_on) e = d.job_draw.reserve(njobs_max);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || fr.chunk <= 1) return fail(PT_ERR_HIP, std::string("job buffers: ") + hipGetErrorString(e));
+        d.L.release(); d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release(); d.job_seg.release(); d.job_draw.release();
+        fr.chunk = std::max<uint32_t>(1, fr.chunk / 2);
+        if (std::getenv("PTCORE_VERBOSE")) std::fprintf(stderr, "ptcore: device %d is short of memory, samples per pass reduced to %u\n", d.ordinal, fr.chunk);
     }
     if (!d.ev_first) {
         HIP_TRY(hipEventCreate(&d.ev_first));

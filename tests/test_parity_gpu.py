@@ -327,3 +327,51 @@ def test_full_size_windows_match_oracle(gpu_ctx, oracle, name, w, h, spp, depth,
         acc2 = np.zeros((h, w, 3))
         hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 64), img2, None, acc2, ctx=gpu_ctx)
         assert np.array_equal(acc, acc2) and np.array_equal(img, img2)
+
+
+def test_job_buffers_shrink_when_the_device_is_short_of_memory():
+    # a job-buffer budget beyond the card's HBM: the library halves the samples per pass until the
+    # buffers fit, and the pixels do not depend on that
+    import os
+
+    from path_trace_golang_amd import capi, hip, scene
+
+    sc = scene.load(scene_path("test_scene"))
+    w, h, spp, depth = 1920, 1080, 4096, 2
+    imgs = []
+    for budget in ("1000000", None):  # 1 TB of job buffers asked for, then the default
+        old = os.environ.pop("PTCORE_L_BUDGET_MB", None)
+        if budget:
+            os.environ["PTCORE_L_BUDGET_MB"] = budget
+        try:
+            with capi.Context(ndev=1) as ctx:
+                img = np.zeros((h, w, 4), np.uint8)
+                st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, 3), img, ctx=ctx)
+                imgs.append((img, st["spp_chunk"], st["segments"]))
+        finally:
+            os.environ.pop("PTCORE_L_BUDGET_MB", None)
+            if old is not None:
+                os.environ["PTCORE_L_BUDGET_MB"] = old
+    assert imgs[0][1] < spp  # 4096 spp per pass would need 760 GB; it was reduced
+    assert np.array_equal(imgs[0][0], imgs[1][0]) and imgs[0][2] == imgs[1][2]
+
+
+@pytest.mark.parametrize("w,h,spp", [(33, 33, 4096), (400, 225, 2048)])
+def test_many_samples_on_ragged_frames(gpu_ctx, oracle, w, h, spp):
+    # Edge tiles hold long runs of jobs whose pixel lies outside the frame (256*S in a row); with thousands of
+    # samples per pass there are more such claims than resident waves.  Every in-frame job must still be traced.
+    from path_trace_golang_amd import capi, hip, scene
+
+    sc = scene.load(scene_path("test_scene"))
+    depth, seed = 2, 5
+    o = oracle.render(oracle.Scene.load(scene_path("test_scene")), w, h, spp, depth, seed=seed)
+    img = np.zeros((h, w, 4), np.uint8)
+    acc = np.zeros((h, w, 3))
+    nseg = np.zeros((h, w), np.uint32)
+    ndraw = np.zeros((h, w), np.uint32)
+    st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg, ndraw,
+                    ctx=gpu_ctx)
+    assert st["spp_chunk"] >= 1024  # thousands of samples in one pass
+    assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"]
+    assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
+    assert np.array_equal(img, o["rgba"])
