@@ -396,6 +396,9 @@ int32_t validate(const pt_scene *scene, const pt_config *cfg) {
     if (cfg->width <= 0 || cfg->height <= 0) return fail(PT_ERR_INVALID, "width and height must be positive");
     if (cfg->samples_per_px < 0) return fail(PT_ERR_INVALID, "samples_per_px must be >= 0");
     if ((int64_t)cfg->width * cfg->height > (int64_t)1 << 28) return fail(PT_ERR_INVALID, "frame too large");
+    // pixel slots are 32-bit: 1024 per 32x32 tile, also for the nearly empty tiles of a 1-pixel-wide frame
+    if ((int64_t)((cfg->width + 31) / 32) * ((cfg->height + 31) / 32) > (int64_t)1 << 21)
+        return fail(PT_ERR_INVALID, "frame too large (more than 2^21 tiles)");
     if (scene->num_materials < 0 || scene->num_objects < 0) return fail(PT_ERR_INVALID, "negative scene counts");
     if (scene->num_materials > 0 && !scene->materials) return fail(PT_ERR_INVALID, "materials is null");
     if (scene->num_objects > 0 && !scene->objects) return fail(PT_ERR_INVALID, "objects is null");

@@ -154,6 +154,11 @@ def test_invalid_arguments_are_errors(gpu_ctx):
     rc = L.pt_render(gpu_ctx.handle, C.byref(flat.c), C.byref(cfg), buf.ctypes.data_as(C.c_void_p), 39, None, None, None,
                      C.byref(st))
     assert rc == capi.PT_ERR_INVALID
+    # 1 x 2^27 pixels would be 2^22 nearly empty tiles: refused before any pointer is touched
+    cfg = hip.pt_config(hip.RenderConfig(1, 1 << 27, 1, 1))
+    rc = L.pt_render(gpu_ctx.handle, C.byref(flat.c), C.byref(cfg), buf.ctypes.data_as(C.c_void_p), 4, None, None, None,
+                     C.byref(st))
+    assert rc == capi.PT_ERR_INVALID and b"too large" in L.pt_last_error()
     assert L.pt_step(gpu_ctx.handle, 1, None) == capi.PT_ERR_STATE  # no frame open
     # a failed call leaves the context usable
     img = np.zeros((10, 10, 4), np.uint8)
@@ -216,6 +221,17 @@ def test_two_virtual_devices_in_process(oracle):
                             ndraw, ctx=ctx)
             assert st["num_devices"] == len(devs)
             _compare(o, img, acc, nseg, ndraw, st, depth)
+    # more devices than tiles: a 40x20 frame is two tiles, the third and fourth device own nothing
+    w, h = 40, 20
+    o = oracle.render(oracle.Scene.load(scene_path("test_comprehensive")), w, h, spp, depth, seed=5)
+    with capi.Context(devices=[0, 0, 0, 0]) as ctx:
+        img = np.zeros((h, w, 4), np.uint8)
+        acc = np.zeros((h, w, 3))
+        nseg = np.zeros((h, w), np.uint32)
+        ndraw = np.zeros((h, w), np.uint32)
+        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, 5, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg, ndraw,
+                        ctx=ctx)
+        _compare(o, img, acc, nseg, ndraw, st, depth)
 
 
 def test_device_tiles_and_untile_entry_points(gpu_ctx, oracle):
