@@ -821,7 +821,16 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             if (take) {
                 // the primary ray of this job was generated by raygen_kernel (coherent pre-pass)
                 const uint32_t nd = B.ray_ndraw[myjob];
-                if (nd != 0xffffu) {  // 0xffff: the job's pixel lies outside the frame (edge tile)
+                if (nd != 0xffffu && F.max_depth <= 0) {
+                    // rayColorOpt returns black before any scan (renderer.go:287-289); the camera draws happened
+                    c_samples++;
+                    c_draw += nd;
+                    reinterpret_cast<double4 *>(B.L)[myjob] = make_double4(0.0, 0.0, 0.0, 0.0);
+                    if (STATS) {
+                        B.job_seg[myjob] = 0;
+                        B.job_draw[myjob] = nd;
+                    }
+                } else if (nd != 0xffffu) {  // 0xffff: the job's pixel lies outside the frame (edge tile)
                     SEC_BEGIN(SEC_RAYGEN)
                     job = myjob;
                     active = true;

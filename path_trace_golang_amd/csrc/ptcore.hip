@@ -553,14 +553,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
         HIP_TRY(hipEventRecord(d.ev_first, d.stream));
         d.first_recorded = true;
     }
-    if (fr.cfg.max_depth <= 0) {
-        // rayColorOpt returns black at depth <= 0 (renderer.go:287-289): nothing to trace
-        HIP_TRY(hipMemsetAsync(d.L.p, 0, 4 * (size_t)F.njobs * sizeof(double), d.stream));
-        if (fr.stats_on) {
-            HIP_TRY(hipMemsetAsync(d.job_seg.p, 0, (size_t)F.njobs * sizeof(uint32_t), d.stream));
-            HIP_TRY(hipMemsetAsync(d.job_draw.p, 0, (size_t)F.njobs * sizeof(uint32_t), d.stream));
-        }
-    } else {
+    {  // ray generation, then the trace kernel (which also handles max_depth <= 0: black samples, camera draws counted)
         HIP_TRY(hipMemsetAsync(d.queue.p, 0, sizeof(unsigned int), d.stream));
         const size_t lds = fr.lds_bytes;
         const uint32_t waves_needed = (F.njobs + 63u) / 64u;

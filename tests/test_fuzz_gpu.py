@@ -84,3 +84,35 @@ def test_random_scenes_all_strategies(contexts, oracle, seed):
             ref = o["accum"]
             ok = (np.isnan(acc) & np.isnan(ref)) | (np.abs(acc - ref) <= 4 * depth * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
             assert np.all(ok), (mode, seed)
+
+
+def test_random_render_configurations_match_oracle(gpu_ctx, oracle):
+    # 40 random (scene file, frame size, spp, depth, chunk, seed) combinations, including 0 spp, depth 0,
+    # 1-pixel frames and chunk sizes that do not divide the sample count
+    from conftest import SCENE_NAMES, scene_path
+    from path_trace_golang_amd import capi, hip, scene
+
+    rng = np.random.default_rng(20241)
+    for case in range(40):
+        name = SCENE_NAMES[int(rng.integers(len(SCENE_NAMES)))]
+        w = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 97, 130]))
+        h = int(rng.choice([1, 3, 8, 24, 32, 40, 65, 90]))
+        spp = int(rng.choice([0, 1, 2, 5, 17, 64]))
+        depth = int(rng.choice([0, 1, 2, 3, 4, 8, 12, 30]))
+        chunk = int(rng.choice([0, 1, 3, 7, 100]))
+        seed = int(rng.integers(1, 1 << 40))
+        sc = scene.load(scene_path(name))
+        o = oracle.render(oracle.Scene.load(scene_path(name)), w, h, spp, depth, seed=seed)
+        img = np.zeros((h, w, 4), np.uint8)
+        acc = np.zeros((h, w, 3))
+        nseg = np.zeros((h, w), np.uint32)
+        ndraw = np.zeros((h, w), np.uint32)
+        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, chunk, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg,
+                        ndraw, ctx=gpu_ctx)
+        tag = "case %d: %s %dx%d spp %d depth %d chunk %d seed %d" % (case, name, w, h, spp, depth, chunk, seed)
+        assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"], tag
+        assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]), tag
+        assert np.array_equal(img, o["rgba"]), tag
+        ref = o["accum"]
+        ok = (np.isnan(acc) & np.isnan(ref)) | (np.abs(acc - ref) <= 4 * max(depth, 1) * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
+        assert np.all(ok), tag
