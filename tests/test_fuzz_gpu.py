@@ -116,3 +116,33 @@ def test_random_render_configurations_match_oracle(gpu_ctx, oracle):
         ref = o["accum"]
         ok = (np.isnan(acc) & np.isnan(ref)) | (np.abs(acc - ref) <= 4 * max(depth, 1) * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
         assert np.all(ok), tag
+
+
+def test_random_large_scenes_match_oracle(gpu_ctx, oracle):
+    # 16 random synthetic scenes beyond the candidate bitmasks (BVH path) at random frame sizes, chunks and depths
+    from path_trace_golang_amd import capi, hip, synth
+
+    rng = np.random.default_rng(77031)
+    for case in range(16):
+        n = int(rng.choice([33, 40, 65, 100, 257, 600, 1500]))
+        w = int(rng.choice([1, 17, 33, 64, 90]))
+        h = int(rng.choice([2, 24, 32, 50]))
+        spp = int(rng.choice([1, 3, 8]))
+        depth = int(rng.choice([1, 3, 6, 10]))
+        chunk = int(rng.choice([0, 1, 2, 5]))
+        seed = int(rng.integers(1, 1 << 40))
+        sc = synth.make_scene(n, int(rng.integers(1, 1000)))
+        o = oracle.render(oracle.Scene(sc.encode()), w, h, spp, depth, seed=seed)
+        img = np.zeros((h, w, 4), np.uint8)
+        acc = np.zeros((h, w, 3))
+        nseg = np.zeros((h, w), np.uint32)
+        ndraw = np.zeros((h, w), np.uint32)
+        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, chunk, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg,
+                        ndraw, ctx=gpu_ctx)
+        tag = "case %d: %d objects %dx%d spp %d depth %d chunk %d seed %d" % (case, n, w, h, spp, depth, chunk, seed)
+        assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"], tag
+        assert st["exit_scans"] == o["stats"]["exit_scans"], tag
+        assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]), tag
+        assert np.array_equal(img, o["rgba"]), tag
+        rel = np.abs(acc - o["accum"]) / np.maximum(np.abs(o["accum"]), 1e-300)
+        assert rel.max() <= 4 * depth * 2.0 ** -52, tag
