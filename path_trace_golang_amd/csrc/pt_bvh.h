@@ -154,8 +154,11 @@ struct Builder {
         return m;
     }
 
-    // binary tree over idx[a, b); returns its node
-    int32_t build(int a, int b) {
+    // binary tree over idx[a, b); returns its node.  Below `sah_levels` levels the split is the median of the
+    // object list (whatever SAH would like): a scene that makes SAH peel off one object per level
+    // (geometrically spaced objects) must not drive the recursion or the traversal stack to depth n.
+    int sah_levels = 40;
+    int32_t build(int a, int b, int level = 0) {
         const int32_t me = (int32_t)bin.size();
         bin.emplace_back();
         if (b - a == 1) {
@@ -163,9 +166,9 @@ struct Builder {
             bin[(size_t)me].box = bounds[(size_t)idx[(size_t)a]];
             return me;
         }
-        const int m = split(a, b);
-        const int32_t l = build(a, m);
-        const int32_t r = build(m, b);
+        const int m = level < sah_levels ? split(a, b) : (a + b) / 2;
+        const int32_t l = build(a, m, level + 1);
+        const int32_t r = build(m, b, level + 1);
         BinNode &nd = bin[(size_t)me];
         nd.left = l;
         nd.right = r;
@@ -205,7 +208,7 @@ struct Builder {
 }  // namespace detail
 
 // `finite` lists the world indices of the spheres and boxes (planes stay outside the tree).
-inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> &finite, double margin) {
+inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> &finite, double margin, int sah_levels = 40) {
     Built out;
     const int n = (int)finite.size();
     if (n == 0) return out;  // no finite objects: the kernel skips the traversal
@@ -220,6 +223,7 @@ inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> 
             bl.cx[k][(size_t)i] = c;
         }
     }
+    bl.sah_levels = sah_levels;
     bl.bin.reserve((size_t)2 * n);
     const int32_t root = bl.build(0, n);
 

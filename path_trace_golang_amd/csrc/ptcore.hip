@@ -730,6 +730,9 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
         const double margin = Bnd * (1.0 / 4096.0);
         ptbvh::Built built = ptbvh::build(w, finite, margin);
         ptbvh::Built builtd = ptbvh::build(w, glass, margin);
+        // a tree too deep for the per-lane stack (adversarial spacing) is rebuilt with fewer SAH levels
+        for (int lv = 16; built.stack_need >= PT_BVH_STACK && lv >= 0; lv -= 16) built = ptbvh::build(w, finite, margin, lv);
+        for (int lv = 16; builtd.stack_need >= PT_BVH_STACK && lv >= 0; lv -= 16) builtd = ptbvh::build(w, glass, margin, lv);
         sd.bvh_depth = std::max(built.depth, builtd.depth);
         sd.bvh_stack_need = std::max(built.stack_need, builtd.stack_need);
         if (sd.bvh_stack_need >= PT_BVH_STACK)
@@ -992,6 +995,7 @@ int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]) {
     }
     const double margin = Bnd * (1.0 / 4096.0);
     ptbvh::Built b = ptbvh::build(world, finite, margin);
+    for (int lv = 16; b.stack_need >= PT_BVH_STACK && lv >= 0; lv -= 16) b = ptbvh::build(world, finite, margin, lv);
     std::vector<int> seen(world.size(), 0);
     int widest = 0, outside = 0, nested = 0;
     struct Item { int32_t node; float lo[3], hi[3]; };

@@ -76,3 +76,33 @@ def test_far_cameras_through_the_bvh(gpu_ctx, oracle, cam_scale):
     assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"]
     assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
     assert np.array_equal(img, o["rgba"])
+
+
+def test_geometrically_spaced_objects(gpu_ctx, oracle):
+    # 200 spheres whose positions and radii grow by 1.2x each (twelve decades): the deepest tree the builder
+    # makes, a scene bound that dwarfs the objects near the camera, and every ray "far" for most of them
+    from path_trace_golang_amd import capi, hip, scene
+
+    objs = [{"type": "plane", "position": {"x": 0, "y": -1, "z": 0}, "material_id": "d"}]
+    for k in range(200):
+        s = 1.2 ** k
+        objs.append({"type": "sphere" if k % 3 else "box", "position": {"x": 0.02 * s, "y": 0.01 * s, "z": -0.05 * s},
+                     "size": {"x": 0.004 * s, "y": 0.004 * s, "z": 0.004 * s}, "material_id": "g" if k % 5 == 0 else "d"})
+    doc = {"camera": {"position": {"x": 0, "y": 0.2, "z": 1.5}, "target": {"x": 0, "y": 0, "z": -1}, "up": {"x": 0, "y": 1, "z": 0},
+                      "fov": 60},
+           "sky": {"type": "gradient", "horizon": {"r": 1, "g": 1, "b": 1}, "zenith": {"r": 0.4, "g": 0.6, "b": 1.0}},
+           "materials": [{"id": "d", "type": "lambert", "albedo": {"r": 0.7, "g": 0.6, "b": 0.5}},
+                         {"id": "g", "type": "dielectric", "ior": 1.5, "albedo": {"r": 1, "g": 1, "b": 1}}],
+           "objects": objs}
+    sc = scene.Scene.decode(doc)
+    w, h, spp, depth, seed = 64, 48, 4, 8, 3
+    o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=seed)
+    img = np.zeros((h, w, 4), np.uint8)
+    nseg = np.zeros((h, w), np.uint32)
+    ndraw = np.zeros((h, w), np.uint32)
+    st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, None, nseg, ndraw,
+                    ctx=gpu_ctx)
+    assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"]
+    assert st["exit_scans"] == o["stats"]["exit_scans"]
+    assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
+    assert np.array_equal(img, o["rgba"])

@@ -95,6 +95,12 @@ def test_bvh_builder_invariants_on_cpu():
 
     lib = capi.load()
     cases = [synth.make_scene(n, 3) for n in (1, 2, 5, 64, 65, 500, 5000)] + [scene.load(scene_path(s)) for s in SCENE_NAMES]
+    # geometrically spaced spheres make SAH peel off one object per level: the builder must bound the depth
+    cases.append(scene.Scene.decode({
+        "camera": {"position": {"x": 0, "y": 1, "z": 6}, "target": {"x": 0, "y": 1, "z": 0}, "up": {"x": 0, "y": 1, "z": 0}, "fov": 50},
+        "materials": [{"id": "d", "type": "lambert", "albedo": {"r": 0.5, "g": 0.5, "b": 0.5}}],
+        "objects": [{"type": "sphere", "position": {"x": 1e-100 * 2.0 ** k, "y": 0, "z": 0}, "size": {"x": 1e-103 * 2.0 ** k, "y": 0, "z": 0},
+                     "material_id": "d"} for k in range(900)]}))
     for sc in cases:
         flat = hip.FlatScene(sc)
         out = (C.c_int32 * 8)()
@@ -103,7 +109,7 @@ def test_bvh_builder_invariants_on_cpu():
         finite = sum(1 for o in sc.objects if o.type in ("sphere", "sphere_light", "box"))
         assert objs == finite and planes == sum(1 for o in sc.objects if o.type == "plane")
         assert bad == 0 and outside == 0 and nested == 0
-        assert slots <= 4 and depth < 48 and nodes >= 1
+        assert slots <= 4 and depth <= 64 and nodes >= 1
 
 
 def test_synthetic_scene_is_reproducible_and_in_schema(tmp_path):
