@@ -127,7 +127,8 @@ struct DevFrame {
     int32_t bvh_main_nodes;           // nodes of the main tree (breadth-first order)
     int32_t bvh_stack;                // traversal stack entries per lane (LDS)
     int32_t bvh_lds_nodes;            // top-level nodes of the main tree staged in LDS
-    int32_t pad_i[2];
+    int32_t bvh_min_lanes;            // a traversal loop with fewer lanes still walking leaves them for the next trip
+    int32_t pad_i[1];
     int32_t broad_ok;    // 1: at most 32 sphere records and 32 box records -> candidate-bitmask scan usable
     uint32_t sph_all, box_all;    // (1 << n_bsph) - 1, (1 << n_bbox) - 1
     uint32_t sph_diel, box_diel;  // records whose object is dielectric (exit searches)

@@ -424,17 +424,35 @@ __device__ __forceinline__ bool bvh_ray_trusted(const DevFrame &F, const RayD &r
 // CAREFUL: some lane of the wave carries clip.infl > 0 (see clip_ray; every node and object bound is then
 // widened by the lane's own infl) or a ray the FP32 bounds were not analysed for (it visits every node).
 // The caller guarantees bvh_ray_trusted() for every lane of a wave it sends to the other instantiation.
+//
+// A traversal can be left unfinished: lanes of one wave need very different numbers of node visits, and a wave
+// that waits for its longest walk runs at a fifth of its lanes.  Once fewer than F.bvh_min_lanes lanes are still
+// walking (and at least one lane of this trip is done), the loop ends; the stragglers keep their state
+// (TravState + their LDS stack column), skip shading, and carry on in the wave's next trip next to the fresh
+// scans of the other lanes.  Returns true when this lane's scan is complete (best / tmax valid).
+struct TravState {
+    int cur = -1;        // node to visit next
+    int sp = 0;
+    int best = -1;
+    double tmax = 0;
+    bool best_is_box = false;
+    bool live = false;   // a traversal of the lane's current ray is in progress
+};
 template <bool PROF, bool CAREFUL, typename ObjPtr, typename IdxPtr>
-__device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr g_pl, const BvhNode *__restrict__ nodes,
+__device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr g_pl, const BvhNode *__restrict__ nodes,
                                          const BvhNode *lds_nodes /* nodes[0 .. F.bvh_lds_nodes) staged in LDS */,
                                          const BvhObj *__restrict__ bobjs, int *stack /* this lane's column, stride PT_BLOCK */,
-                                         const RayD &r, const Clip &clip, int mode, int &best, double &tmax, const ProfHooks &ph) {
+                                         const RayD &r, const Clip &clip, int mode, TravState &S, int &best, double &tmax,
+                                         const ProfHooks &ph) {
     const double tmin = mode ? 0.0001 : 0.001;
-    tmax = ptm::max_float64();
-    best = -1;
-    bool best_is_box = false;
+    const bool resume = S.live;
+    S.live = false;
+    tmax = resume ? S.tmax : ptm::max_float64();
+    best = resume ? S.best : -1;
+    bool best_is_box = resume ? S.best_is_box : false;
     const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
 
+    if (!resume) {
     PH_BEGIN(SEC_PLANE)
     for (int k = 0; k < F.n_plane; k++) {
         const int i = g_pl[k];
@@ -451,13 +469,14 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
         }
     }
     PH_END(SEC_PLANE)
+    }
     const int root = mode ? F.bvh_root_exit : F.bvh_root;
-    if (root < 0) return;
+    if (root < 0) return true;
 
     const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
     // rays from outside the scene cube: a miss ends the scan, the others start their FP32 node tests at the
     // entry point (clip_ray); parameters below are relative to ts
-    if (clip.miss || clip.te > tmax) return;
+    if (!resume && (clip.miss || clip.te > tmax)) return true;
     const double ts = clip.ts;
     const float fox = (float)(r.ox + r.dx * ts), foy = (float)(r.oy + r.dy * ts), foz = (float)(r.oz + r.dz * ts);
     const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
@@ -479,14 +498,18 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     const float exf = inflf * __builtin_fabsf(ivxf), eyf = inflf * __builtin_fabsf(ivyf), ezf = inflf * __builtin_fabsf(ivzf);
     float tmaxf = (float)(tmax - ts);
     tmaxf += __builtin_fabsf(tmaxf) * 4.8e-7f;  // >= tmax - ts (MaxFloat64 becomes +inf)
-    int sp = 0;
-    int cur = root;            // node to visit next, -1 when this lane has none left
+    int sp = resume ? S.sp : 0;
+    int cur = resume ? S.cur : root;  // node to visit next, -1 when this lane has none left
     uint32_t pend = 0;         // slots of the last visited node whose object still awaits its exact test
     uint32_t pend_meta = 0;
     int pend_base = 0;
     uint32_t n_leaf = 0;  // PROF only: object batches this lane went through
     PH_BEGIN(SEC_BROAD)
-    while (__ballot(cur >= 0) != 0) {
+    const int n_start = __popcll(__ballot(1));
+    for (;;) {
+        const int walking = __popcll(__ballot(cur >= 0));
+        if (walking == 0) break;
+        if (walking < F.bvh_min_lanes && walking < n_start) break;  // stragglers carry on in the next trip
         // ---- walk internal nodes until this lane holds objects to test (or has nothing left)
         while (cur >= 0) {
             if (PROF) ph.lanes[SEC_NBOX]++;  // node visits (lane count)
@@ -599,6 +622,15 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
         }
     }
     PH_END(SEC_BROAD)
+    if (cur >= 0) {  // unfinished: keep the walk for the next trip
+        S.live = true;
+        S.cur = cur;
+        S.sp = sp;
+        S.best = best;
+        S.tmax = tmax;
+        S.best_is_box = best_is_box;
+        return false;
+    }
     if (PROF) {
         // histogram of object batches per scan: bins <4, <16, <64, <256, <1024, >=1024 (closest-hit scans in
         // the `exec` counters of three otherwise unused section ids and their `cyc` words, exit searches in `lanes`)
@@ -620,6 +652,7 @@ __device__ __forceinline__ void scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
             ph.lanes[id]++;
         }
     }
+    return true;
 }
 
 // Ray generation pre-pass: one thread per job of the chunk, all lanes busy and neighbouring
@@ -766,6 +799,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
     uint32_t c_seg = 0, c_exit = 0, c_draw = 0, c_samples = 0;
     uint32_t j_seg = 0, j_draw = 0;
     uint32_t c_mismatch = 0;  // SCAN_VERIFY only
+    TravState trav;           // BVH strategies only: an unfinished traversal of this lane's ray
 
     // wave-uniform job cursor
     uint32_t cur = 0, end = 0;
@@ -863,13 +897,14 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         bool finished = false;
         double termx = 0, termy = 0, termz = 0;
 
+        int best = -1;
+        double tmax = 0;
+        bool scanned = true;  // false: this lane's BVH walk goes on in the next trip, nothing to shade yet
         if (active) {
             // -------------------------------------------------------- scan
             SEC_BEGIN(SEC_SCAN)
             const RayD ray{ox, oy, oz, dx, dy, dz};
             const ProfHooks ph{p_exec, p_lanes, p_cyc, lane, B.counters + 8};
-            int best;
-            double tmax;
             if (SCAN == SCAN_UNIFORM) {
                 scan_uniform(F, g_obj, ray, mode, best, tmax);
             } else {
@@ -887,16 +922,17 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 constexpr bool VERIFY = (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_BVH);
                 if (plain) {
                     scan_uniform(F, g_obj, ray, mode, best, tmax);
+                    trav.live = false;  // a complete answer: whatever walk was pending is obsolete
                 } else {
                     if (BITMASK)
                         scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
                     else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
-                        scan_bvh<PROF, true>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, clip,
-                                             mode, best, tmax, ph);
+                        scanned = scan_bvh<PROF, true>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x,
+                                                       ray, clip, mode, trav, best, tmax, ph);
                     else
-                        scan_bvh<PROF, false>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, clip,
-                                              mode, best, tmax, ph);
-                    if (VERIFY) {
+                        scanned = scan_bvh<PROF, false>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x,
+                                                        ray, clip, mode, trav, best, tmax, ph);
+                    if (VERIFY && scanned) {
                         int best2;
                         double tmax2;
                         scan_uniform(F, g_obj, ray, mode, best2, tmax2);
@@ -916,6 +952,8 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 }
             }
             SEC_END(SEC_SCAN)
+        }
+        if (active && scanned) {
             // -------------------------------------------------------- shade
             bool do_rr = false;
             double attx = 1, atty = 1, attz = 1;
