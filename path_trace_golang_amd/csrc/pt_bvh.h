@@ -91,7 +91,8 @@ struct Builder {
     std::vector<BinNode> bin;
     double margin;
 
-    // chooses the split position inside [a, b): binned SAH over the largest centroid axis, median fallback
+    // chooses the split position inside [a, b): binned SAH (16 bins) over each centroid axis, the cheapest of the
+    // three wins; median of the widest axis when no bin boundary separates the objects
     int split(int a, int b) {
         Aabb cb;
         cb.reset();
@@ -101,54 +102,58 @@ struct Builder {
                 cb.lo[k] = std::min(cb.lo[k], c);
                 cb.hi[k] = std::max(cb.hi[k], c);
             }
-        int axis = 0;
+        int wide = 0;
         double ext = -1;
         for (int k = 0; k < 3; k++) {
             const double e = cb.hi[k] - cb.lo[k];
-            if (e == e && e > ext && std::isfinite(e)) { ext = e; axis = k; }
+            if (e == e && e > ext && std::isfinite(e)) { ext = e; wide = k; }
         }
         const int mid = (a + b) / 2;
-        auto by_axis = [&](int32_t u, int32_t v) { return cx[axis][(size_t)u] < cx[axis][(size_t)v]; };
         if (!(ext > 0)) return mid;  // all centroids coincide (or are not finite): any split is as good
         constexpr int NB = 16;
-        Aabb bb[NB];
-        int cnt[NB];
-        for (int i = 0; i < NB; i++) { bb[i].reset(); cnt[i] = 0; }
-        const double scale = NB / ext;
-        auto bin_of = [&](int32_t o) {
-            const int q = (int)((cx[axis][(size_t)o] - cb.lo[axis]) * scale);
-            return std::max(0, std::min(NB - 1, q));
-        };
-        for (int i = a; i < b; i++) {
-            const int32_t o = idx[(size_t)i];
-            const int q = bin_of(o);
-            bb[q].grow(bounds[(size_t)o]);
-            cnt[q]++;
-        }
         double best = INFINITY;
-        int best_bin = -1;
-        Aabb right[NB];
-        int rc[NB];
-        Aabb acc;
-        acc.reset();
-        int n = 0;
-        for (int i = NB - 1; i >= 0; i--) { acc.grow(bb[i]); n += cnt[i]; right[i] = acc; rc[i] = n; }
-        acc.reset();
-        n = 0;
-        for (int i = 0; i + 1 < NB; i++) {
-            acc.grow(bb[i]);
-            n += cnt[i];
-            if (n == 0 || rc[i + 1] == 0) continue;
-            const double cost = acc.area() * n + right[i + 1].area() * rc[i + 1];
-            if (cost < best) { best = cost; best_bin = i; }
+        int best_bin = -1, best_axis = -1;
+        double best_scale = 0;
+        for (int axis = 0; axis < 3; axis++) {
+            const double e = cb.hi[axis] - cb.lo[axis];
+            if (!(e > 0) || !std::isfinite(e)) continue;
+            Aabb bb[NB];
+            int cnt[NB];
+            for (int i = 0; i < NB; i++) { bb[i].reset(); cnt[i] = 0; }
+            const double scale = NB / e;
+            for (int i = a; i < b; i++) {
+                const int32_t o = idx[(size_t)i];
+                const int q = std::max(0, std::min(NB - 1, (int)((cx[axis][(size_t)o] - cb.lo[axis]) * scale)));
+                bb[q].grow(bounds[(size_t)o]);
+                cnt[q]++;
+            }
+            Aabb right[NB];
+            int rc[NB];
+            Aabb acc;
+            acc.reset();
+            int n = 0;
+            for (int i = NB - 1; i >= 0; i--) { acc.grow(bb[i]); n += cnt[i]; right[i] = acc; rc[i] = n; }
+            acc.reset();
+            n = 0;
+            for (int i = 0; i + 1 < NB; i++) {
+                acc.grow(bb[i]);
+                n += cnt[i];
+                if (n == 0 || rc[i + 1] == 0) continue;
+                const double cost = acc.area() * n + right[i + 1].area() * rc[i + 1];
+                if (cost < best) { best = cost; best_bin = i; best_axis = axis; best_scale = scale; }
+            }
         }
         int m = mid;
         if (best_bin >= 0 && std::isfinite(best)) {
-            auto it = std::partition(idx.begin() + a, idx.begin() + b, [&](int32_t o) { return bin_of(o) <= best_bin; });
+            const double lo = cb.lo[best_axis];
+            auto it = std::partition(idx.begin() + a, idx.begin() + b, [&](int32_t o) {
+                return std::max(0, std::min(NB - 1, (int)((cx[best_axis][(size_t)o] - lo) * best_scale))) <= best_bin;
+            });
             m = (int)(it - idx.begin());
         }
         if (m <= a || m >= b) {
-            std::nth_element(idx.begin() + a, idx.begin() + mid, idx.begin() + b, by_axis);
+            std::nth_element(idx.begin() + a, idx.begin() + mid, idx.begin() + b,
+                             [&](int32_t u, int32_t v) { return cx[wide][(size_t)u] < cx[wide][(size_t)v]; });
             m = mid;
         }
         return m;
