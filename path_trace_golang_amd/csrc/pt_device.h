@@ -71,15 +71,15 @@ static_assert(sizeof(BroadBox) == 32, "BroadBox layout");
 // node are node_base + rank, its object children bvh_objs[obj_base + rank].
 //   meta bits 0-7: rank of slot s within its kind at bits [2s, 2s+2); 8-11: slot is an internal node;
 //   12-15: slot is an object; 16-19: slot is NOT an internal node (complement of 8-11).
-struct alignas(16) BvhNode {
+struct alignas(128) BvhNode {   // one 128-byte cache line per node (112 bytes used)
     float lo[3][4];   // [axis][slot]
     float hi[3][4];
     int32_t node_base;
     int32_t obj_base;
     uint32_t meta;
-    int32_t pad;
+    int32_t pad[5];
 };
-static_assert(sizeof(BvhNode) == 112, "BvhNode layout");
+static_assert(sizeof(BvhNode) == 128, "BvhNode layout");
 
 // Object as stored in node order for the BVH path: the 80-byte DevObj plus its index in file order
 // (tie rules and the winner look-up use the original index).
