@@ -106,3 +106,32 @@ def test_geometrically_spaced_objects(gpu_ctx, oracle):
     assert st["exit_scans"] == o["stats"]["exit_scans"]
     assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
     assert np.array_equal(img, o["rgba"])
+
+
+def test_straggler_threshold_does_not_change_pixels(oracle):
+    # PTCORE_BVH_MIN_LANES decides when unfinished walks are put off to the wave's next trip (0: never,
+    # 64: as soon as any lane is done); it is a scheduling knob only
+    import os
+
+    from path_trace_golang_amd import capi, hip, synth
+
+    sc = synth.make_scene(700, 21)
+    w, h, spp, depth, seed = 96, 64, 4, 8, 2
+    o = oracle.render(oracle.Scene(sc.encode()), w, h, spp, depth, seed=seed)
+    old = os.environ.get("PTCORE_BVH_MIN_LANES")
+    try:
+        for t in ("0", "1", "8", "40", "64"):
+            os.environ["PTCORE_BVH_MIN_LANES"] = t
+            with capi.Context(ndev=1) as ctx:
+                img = np.zeros((h, w, 4), np.uint8)
+                nseg = np.zeros((h, w), np.uint32)
+                ndraw = np.zeros((h, w), np.uint32)
+                st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, None, nseg,
+                                ndraw, ctx=ctx)
+                assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"], t
+                assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]), t
+                assert np.array_equal(img, o["rgba"]), t
+    finally:
+        os.environ.pop("PTCORE_BVH_MIN_LANES", None)
+        if old is not None:
+            os.environ["PTCORE_BVH_MIN_LANES"] = old
