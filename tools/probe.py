@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Quick throughput probe of the scene files at reduced sample counts (one GPU): python tools/probe.py"""
 import sys, time, numpy as np
 sys.path.insert(0,'.')
 from path_trace_golang_amd import capi, hip, scene
