@@ -24,6 +24,7 @@ import (
 	"fmt"
 	"image"
 	"os"
+	"runtime"
 	"strconv"
 	"sync"
 	"unsafe"
@@ -197,8 +198,14 @@ func Render(sc *scene.Scene, cfg RenderConfig, img *image.RGBA, progress func())
 	if b.Dx() != cfg.Width || b.Dy() != cfg.Height {
 		return nil // renderIntoCPU silently returns on a size mismatch (renderer.go:46-49)
 	}
+	if len(img.Pix) == 0 {
+		return errors.New("hip.Render: empty image")
+	}
 	mu.Lock()
 	defer mu.Unlock()
+	// pt_last_error() is thread-local on the C side: stay on one OS thread from a failing call to its message
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	if err := ensure(); err != nil {
 		return err
 	}
@@ -232,6 +239,12 @@ func Render(sc *scene.Scene, cfg RenderConfig, img *image.RGBA, progress func())
 			break
 		}
 		progress()
+	}
+	if err == nil && cfg.SamplesPerPx <= 0 {
+		// zero samples: the reference's pixel finish of an empty sum (renderer.go:190-221)
+		if rc := C.pt_read(ctx, pix, C.int32_t(img.Stride), nil); rc != C.PT_OK {
+			err = lastError("pt_read")
+		}
 	}
 	if rc := C.pt_end(ctx, nil); rc != C.PT_OK && err == nil {
 		err = lastError("pt_end")
