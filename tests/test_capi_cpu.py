@@ -121,3 +121,46 @@ def test_synthetic_scene_is_reproducible_and_in_schema(tmp_path):
     p = str(tmp_path / "synth.json")
     scene.save(p, a)
     assert scene.load(p) == a  # same JSON schema as the reference's scene files
+
+
+def test_header_is_plain_c_and_matches_the_ctypes_mirror(tmp_path):
+    # cgo compiles include/ptcore.h as C: build a C99 consumer with gcc (pedantic, warnings are errors), link it
+    # against libptcore.so, and compare the struct sizes it sees with the ctypes mirror used by the tests
+    import ctypes as C
+    import subprocess
+
+    from path_trace_golang_amd import build, capi
+
+    lib = build.build_core()
+    src = tmp_path / "consumer.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "ptcore.h"
+int main(void) {
+    /* every entry point a cgo binding may name must be declared with a C prototype */
+    typedef void (*fn_t)(void);
+    fn_t fns[] = {(fn_t)pt_abi_version, (fn_t)pt_last_error, (fn_t)pt_device_count, (fn_t)pt_create, (fn_t)pt_destroy,
+                  (fn_t)pt_render, (fn_t)pt_begin, (fn_t)pt_step, (fn_t)pt_read, (fn_t)pt_end, (fn_t)pt_shard_tiles,
+                  (fn_t)pt_render_tiles_device, (fn_t)pt_untile_device, (fn_t)pt_post_process};
+    pt_ctx *ctx = 0;
+    int rc = pt_create(0, 1, &ctx);
+    printf("%d %d %d %d %d %d %d %d %d %d\n", (int)pt_abi_version(), (int)sizeof(pt_material), (int)sizeof(pt_object),
+           (int)sizeof(pt_camera), (int)sizeof(pt_sky), (int)sizeof(pt_scene), (int)sizeof(pt_config),
+           (int)sizeof(pt_shard), (int)sizeof(pt_stats), (int)sizeof(pt_post_config));
+    printf("%d %d\n", rc, (int)(sizeof fns / sizeof fns[0]));
+    if (rc == PT_OK) pt_destroy(ctx); else printf("%s\n", pt_last_error());
+    return 0;
+}
+''')
+    exe = tmp_path / "consumer"
+    libdir = os.path.dirname(lib)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe), "-L", libdir, "-lptcore", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = [int(x) for x in out[0].split()]
+    want = [capi.load().pt_abi_version()] + [C.sizeof(t) for t in (capi.PtMaterial, capi.PtObject, capi.PtCamera, capi.PtSky,
+                                                                   capi.PtScene, capi.PtConfig, capi.PtShard, capi.PtStats,
+                                                                   capi.PtPostConfig)]
+    assert got == want
+    rc = int(out[1].split()[0])
+    assert rc in (capi.PT_OK, capi.PT_ERR_NO_DEVICE)  # no GPU in the CPU container: an error code and a message, not an abort
