@@ -164,3 +164,23 @@ int main(void) {
     assert got == want
     rc = int(out[1].split()[0])
     assert rc in (capi.PT_OK, capi.PT_ERR_NO_DEVICE)  # no GPU in the CPU container: an error code and a message, not an abort
+
+
+def test_go_binding_names_match_the_header():
+    # the cgo sources cannot be compiled here (no Go toolchain); at least every C field, constant and function
+    # they name must exist in include/ptcore.h (cgo spells the C field `type` as `_type`)
+    text = open(os.path.join(ROOT, "include", "ptcore.h")).read()
+    structs = {}
+    for m in re.finditer(r"typedef struct (?:\w+ )?\{(.*?)\} (\w+);", text, re.S):
+        body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+        structs[m.group(2)] = set(re.findall(r"(\w+)(?:\[[^\]]*\])*\s*;", body))
+    names = set(re.findall(r"\b(pt_\w+|PT_\w+)\b", re.sub(r"/\*.*?\*/", "", text, flags=re.S)))
+    go = "".join(open(os.path.join(ROOT, "go", *p)).read() for p in (("internal", "engine", "hip", "hip.go"), ("cmd", "render", "main.go")))
+    for struct, pat in (("pt_material", r"ms\[i\]\.(\w+)"), ("pt_object", r"os_\[i\]\.(\w+)"), ("pt_camera", r"cs\.camera\.(\w+)"),
+                        ("pt_sky", r"cs\.sky\.(\w+)")):
+        used = {x.lstrip("_") for x in re.findall(pat, go)}
+        assert used and used <= structs[struct], (struct, used - structs[struct])
+    cfg_fields = set(re.findall(r"(\w+):\s*C\.", re.findall(r"C\.pt_config\{(.*?)\}", go, re.S)[0]))
+    assert cfg_fields and cfg_fields <= structs["pt_config"]
+    used = set(re.findall(r"C\.(pt_\w+|PT_\w+)", go))
+    assert used <= names, used - names
