@@ -54,14 +54,15 @@ struct alignas(16) BroadSphere {
     float cx, cy, cz;
     float rm2;         // (radius + m)^2, rounded up
     int32_t index;     // object index = bit in the candidate mask
-    int32_t pad[3];
+    int32_t diel;      // 1: the object is dielectric (grouped scan: the exit-search mask is built on the fly)
+    int32_t pad[2];
 };
 static_assert(sizeof(BroadSphere) == 32, "BroadSphere layout");
 struct alignas(16) BroadBox {
     float lo[3];       // min - m, rounded down
     float hi[3];       // max + m, rounded up
     int32_t index;
-    int32_t pad;
+    int32_t diel;      // 1: the object is dielectric
 };
 static_assert(sizeof(BroadBox) == 32, "BroadBox layout");
 
@@ -129,7 +130,8 @@ struct DevFrame {
     int32_t bvh_lds_nodes;            // top-level nodes of the main tree staged in LDS
     int32_t bvh_min_lanes;            // a traversal loop with fewer lanes still walking leaves them for the next trip
     int32_t pad_i[1];
-    int32_t broad_ok;    // 1: at most 32 sphere records and 32 box records -> candidate-bitmask scan usable
+    int32_t broad_ok;    // 1: at most 32 sphere records and 32 box records -> candidate-bitmask scan usable;
+                         // 2: at most 128 of each -> the same in groups of 32 (SCAN_BROAD_WIDE)
     uint32_t sph_all, box_all;    // (1 << n_bsph) - 1, (1 << n_bbox) - 1
     uint32_t sph_diel, box_diel;  // records whose object is dielectric (exit searches)
     float origin_bound;  // rays whose origin leaves [-origin_bound, origin_bound]^3 keep every candidate

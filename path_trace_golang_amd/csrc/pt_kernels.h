@@ -15,6 +15,7 @@
 //                                   builds a per-lane candidate bitmask, then each lane runs
 //                                   the exact FP64 tests only on its own candidates (per-lane
 //                                   look-ups in the LDS copy of the world).  Needs <= 32 spheres and <= 32 boxes.
+//                     SCAN_BROAD_WIDE  the same in groups of 32 records, up to 128 spheres and 128 boxes.
 //                     SCAN_BVH      larger scenes: per-lane traversal of a 4-wide BVH whose FP32
 //                                   slot boxes are conservative (same inflation as the broad phase);
 //                                   a slot is an internal node or one object, the exact FP64 test
@@ -99,7 +100,7 @@ enum { SEC_ITER = 0, SEC_RAYGEN /* loading the pre-generated ray */, SEC_HIST0 /
        SEC_DIEL, SEC_EXITPOST, SEC_RR, SEC_FINISH, SEC_SKY, SEC_UNITDIR, SEC_BROAD, SEC_NSPH, SEC_NBOX, SEC_PLANE, SEC_COUNT };
 
 
-enum { SCAN_UNIFORM = 0, SCAN_BROAD = 1, SCAN_VERIFY = 2, SCAN_BVH = 3, SCAN_VERIFY_BVH = 4 };
+enum { SCAN_UNIFORM = 0, SCAN_BROAD = 1, SCAN_VERIFY = 2, SCAN_BVH = 3, SCAN_VERIFY_BVH = 4, SCAN_BROAD_WIDE = 5, SCAN_VERIFY_WIDE = 6 };
 #define PT_BVH_STACK 96  // upper bound of the per-lane stack (sized per scene from the tree)
 
 // Diagnostic hooks handed to the scan routines (all no-ops unless PROF).
@@ -405,6 +406,131 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
                 tmax = acc ? t : tmax;
                 best_is_box = acc ? true : best_is_box;
                 PH_END(SEC_NBOX)
+            }
+        }
+    }
+}
+
+// The same broad / narrow scan for up to 128 spheres and 128 boxes: the records are taken in groups of 32 (one
+// candidate mask at a time, so no more registers than the single-group version), the dielectric mask of a
+// group is collected from the records on the scalar unit.  Between ~33 and ~200 objects this linear scan at
+// full lanes beats the hierarchy, whose walks diverge.
+template <bool PROF, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
+__device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr g_obj, SphPtr g_bs, BoxPtr g_bb, IdxPtr g_pl,
+                                                       const DevObj *s_obj, const int *s_kidx, const RayD &r, const Clip &clip,
+                                                       int mode, int &best, double &tmax, const ProfHooks &ph) {
+    const double tmin = mode ? 0.0001 : 0.001;
+    tmax = ptm::max_float64();
+    best = -1;
+    bool best_is_box = false;
+    const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+
+    PH_BEGIN(SEC_PLANE)
+    for (int k = 0; k < F.n_plane; k++) {
+        const int i = g_pl[k];
+        const auto &o = g_obj[i];
+        if (mode != 0 && !(o.kind & 0x100)) continue;
+        double t = 0;
+        if (plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t)) {
+            if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
+                          : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_PLANE, r, t))) {
+                best = i;
+                tmax = t;
+                best_is_box = false;
+            }
+        }
+    }
+    PH_END(SEC_PLANE)
+
+    const double ts = clip.ts;
+    const bool outside_all = clip.miss || clip.te > tmax;
+    const float fox = (float)(r.ox + r.dx * ts), foy = (float)(r.oy + r.dy * ts), foz = (float)(r.oz + r.dz * ts);
+    const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
+    const float fa = __builtin_fmaf(fdx, fdx, __builtin_fmaf(fdy, fdy, fdz * fdz));
+    const bool trust = (fa > 1e-30f) && (fa < 1e30f) && (__builtin_fabsf(fox) <= F.origin_bound) &&
+                       (__builtin_fabsf(foy) <= F.origin_bound) && (__builtin_fabsf(foz) <= F.origin_bound);
+    float tminf = (float)(tmin - ts);
+    tminf -= __builtin_fabsf(tminf) * 1e-2f + 1e-6f;
+    const float inv_a = __builtin_amdgcn_rcpf(fa);
+    const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
+    const float noxf = -fox * ivxf, noyf = -foy * ivyf, nozf = -foz * ivzf;
+
+    for (int base = 0; base < F.n_bsph; base += 32) {
+        const int cnt = F.n_bsph - base < 32 ? F.n_bsph - base : 32;
+        PH_BEGIN(SEC_BROAD)
+        uint32_t cs = 0, diel = 0;
+        for (int k = 0; k < cnt; k++) {
+            const auto &s = g_bs[base + k];
+            const float ocx = fox - s.cx, ocy = foy - s.cy, ocz = foz - s.cz;
+            const float b = __builtin_fmaf(ocx, fdx, __builtin_fmaf(ocy, fdy, ocz * fdz));
+            const float tca = -b * inv_a;
+            const float qx = __builtin_fmaf(fdx, tca, ocx), qy = __builtin_fmaf(fdy, tca, ocy), qz = __builtin_fmaf(fdz, tca, ocz);
+            const float d2 = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
+            const float rem = s.rm2 - d2;
+            const float w = __builtin_fmaxf(tminf - tca, 0.0f);
+            const bool miss = rem < w * w * fa;
+            cs = miss ? cs : (cs | (1u << k));
+            diel |= s.diel ? (1u << k) : 0u;  // wave-uniform: scalar unit
+        }
+        if (!trust) cs = cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+        if (outside_all) cs = 0;
+        if (mode != 0) cs &= diel;
+        PH_END(SEC_BROAD)
+        while (__ballot(cs != 0) != 0) {
+            if (cs != 0) {
+                PH_BEGIN(SEC_NSPH)
+                const int i = s_kidx[base + __builtin_ctz(cs)];
+                cs &= cs - 1;
+                const DevObj &o = s_obj[i];
+                double t = 0;
+                bool acc = sphere_exact(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, tmin, tmax, t) &&
+                           wins(mode, false, i, t, best, best_is_box, tmax);
+                if (acc && mode != 0) acc = exit_candidate_ok(o, KIND_SPHERE, r, t);
+                best = acc ? i : best;
+                tmax = acc ? t : tmax;
+                best_is_box = acc ? false : best_is_box;
+                PH_END(SEC_NSPH)
+            }
+        }
+    }
+    if (F.n_bbox > 0) {
+        const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
+        for (int base = 0; base < F.n_bbox; base += 32) {
+            const int cnt = F.n_bbox - base < 32 ? F.n_bbox - base : 32;
+            PH_BEGIN(SEC_BROAD)
+            uint32_t cb = 0, diel = 0;
+            for (int k = 0; k < cnt; k++) {
+                const auto &bx = g_bb[base + k];
+                const float tax = __builtin_fmaf(bx.lo[0], ivxf, noxf), tbx = __builtin_fmaf(bx.hi[0], ivxf, noxf);
+                const float tay = __builtin_fmaf(bx.lo[1], ivyf, noyf), tby = __builtin_fmaf(bx.hi[1], ivyf, noyf);
+                const float taz = __builtin_fmaf(bx.lo[2], ivzf, nozf), tbz = __builtin_fmaf(bx.hi[2], ivzf, nozf);
+                const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)),
+                                                 __builtin_fmaxf(__builtin_fminf(taz, tbz), tminf));
+                const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
+                                                 __builtin_fmaxf(taz, tbz));
+                const bool miss = t1 < t0;
+                cb = miss ? cb : (cb | (1u << k));
+                diel |= bx.diel ? (1u << k) : 0u;
+            }
+            if (!trust) cb = cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+            if (outside_all) cb = 0;
+            if (mode != 0) cb &= diel;
+            PH_END(SEC_BROAD)
+            while (__ballot(cb != 0) != 0) {
+                if (cb != 0) {
+                    PH_BEGIN(SEC_NBOX)
+                    const int i = s_kidx[F.n_bsph + base + __builtin_ctz(cb)];
+                    cb &= cb - 1;
+                    const DevObj &o = s_obj[i];
+                    double t = 0;
+                    bool acc = box_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t) &&
+                               wins(mode, true, i, t, best, best_is_box, tmax);
+                    if (acc && mode != 0) acc = exit_candidate_ok(o, KIND_BOX, r, t);
+                    best = acc ? i : best;
+                    tmax = acc ? t : tmax;
+                    best_is_box = acc ? true : best_is_box;
+                    PH_END(SEC_NBOX)
+                }
             }
         }
     }
@@ -766,7 +892,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         uint64_t *l1 = reinterpret_cast<uint64_t *>(lds_mat);
         const int n1 = F.nmat * (int)(sizeof(DevMat) / 8);
         for (int i = threadIdx.x; i < n1; i += PT_BLOCK) l1[i] = g1[i];
-        if (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY) {
+        if (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY || SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE) {
             for (int i = threadIdx.x; i < F.n_bsph; i += PT_BLOCK) lds_kidx[i] = B.bsph[i].index;
             for (int i = threadIdx.x; i < F.n_bbox; i += PT_BLOCK) lds_kidx[F.n_bsph + i] = B.bbox[i].index;
         }
@@ -915,16 +1041,19 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 // second: the bitmask strategy treats them the same way, the BVH widens its bounds for them.
                 const double a_ = dx * dx + dy * dy + dz * dz;
                 const Clip clip = clip_ray(F, ray, mode ? 0.0001 : 0.001);
-                constexpr bool BITMASK = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY);
+                constexpr bool WIDE = (SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE);
+                constexpr bool BITMASK = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY || WIDE);
                 const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
                                   (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100) && !(BITMASK && clip.far);
                 const bool plain = __ballot(!tame) != 0;
-                constexpr bool VERIFY = (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_BVH);
+                constexpr bool VERIFY = (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_BVH || SCAN == SCAN_VERIFY_WIDE);
                 if (plain) {
                     scan_uniform(F, g_obj, ray, mode, best, tmax);
                     trav.live = false;  // a complete answer: whatever walk was pending is obsolete
                 } else {
-                    if (BITMASK)
+                    if (WIDE)
+                        scan_broad_narrow_wide<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
+                    else if (BITMASK)
                         scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
                     else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
                         scanned = scan_bvh<PROF, true>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x,

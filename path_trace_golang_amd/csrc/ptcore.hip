@@ -358,6 +358,7 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
             s.rm2 = round_up_f(rm * rm);
             if (!(s.rm2 == s.rm2)) s.rm2 = INFINITY;
             s.index = (int32_t)i;
+            s.diel = (o.kind & 0x100) ? 1 : 0;
             if (fr.bsph.size() < 32 && (o.kind & 0x100)) F.sph_diel |= 1u << fr.bsph.size();
             fr.bsph.push_back(s);
         } else if (kind == KIND_BOX) {
@@ -369,6 +370,7 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
                 b.hi[k] = (hi == hi) ? round_up_f(hi) : INFINITY;
             }
             b.index = (int32_t)i;
+            b.diel = (o.kind & 0x100) ? 1 : 0;
             if (fr.bbox.size() < 32 && (o.kind & 0x100)) F.box_diel |= 1u << fr.bbox.size();
             fr.bbox.push_back(b);
         } else {
@@ -378,7 +380,7 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     F.n_bsph = (int32_t)fr.bsph.size();
     F.n_bbox = (int32_t)fr.bbox.size();
     F.n_plane = (int32_t)fr.plane_idx.size();
-    F.broad_ok = (fr.bsph.size() <= 32 && fr.bbox.size() <= 32) ? 1 : 0;
+    F.broad_ok = (fr.bsph.size() <= 32 && fr.bbox.size() <= 32) ? 1 : (fr.bsph.size() <= 128 && fr.bbox.size() <= 128) ? 2 : 0;
     F.sph_all = fr.bsph.size() >= 32 ? 0xffffffffu : ((1u << fr.bsph.size()) - 1u);
     F.box_all = fr.bbox.size() >= 32 ? 0xffffffffu : ((1u << fr.bbox.size()) - 1u);
     F.origin_bound = (float)std::min(4.0 * B, 3.0e38);
@@ -415,11 +417,14 @@ TraceFn pick_trace(bool stats, bool prof, int scan) {
     if (prof) {
         if (scan == SCAN_UNIFORM) return trace_kernel<false, true, SCAN_UNIFORM>;
         if (scan == SCAN_BVH || scan == SCAN_VERIFY_BVH) return trace_kernel<false, true, SCAN_BVH>;
+        if (scan == SCAN_BROAD_WIDE || scan == SCAN_VERIFY_WIDE) return trace_kernel<false, true, SCAN_BROAD_WIDE>;
         return trace_kernel<false, true, SCAN_BROAD>;
     }
     switch (scan) {
         case SCAN_BROAD: return stats ? trace_kernel<true, false, SCAN_BROAD> : trace_kernel<false, false, SCAN_BROAD>;
         case SCAN_VERIFY: return stats ? trace_kernel<true, false, SCAN_VERIFY> : trace_kernel<false, false, SCAN_VERIFY>;
+        case SCAN_BROAD_WIDE: return stats ? trace_kernel<true, false, SCAN_BROAD_WIDE> : trace_kernel<false, false, SCAN_BROAD_WIDE>;
+        case SCAN_VERIFY_WIDE: return stats ? trace_kernel<true, false, SCAN_VERIFY_WIDE> : trace_kernel<false, false, SCAN_VERIFY_WIDE>;
         case SCAN_BVH: return stats ? trace_kernel<true, false, SCAN_BVH> : trace_kernel<false, false, SCAN_BVH>;
         case SCAN_VERIFY_BVH: return stats ? trace_kernel<true, false, SCAN_VERIFY_BVH> : trace_kernel<false, false, SCAN_VERIFY_BVH>;
         default: return stats ? trace_kernel<true, false, SCAN_UNIFORM> : trace_kernel<false, false, SCAN_UNIFORM>;
@@ -702,9 +707,16 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     build_broad(sd.world, sd);
     // closest-hit strategy: at most 32 spheres and 32 boxes -> candidate bitmasks; more -> BVH.  PTCORE_SCAN overrides.
     int scan = ctx->scan_mode;
-    if (scan < 0) scan = F.broad_ok ? ptk::SCAN_BROAD : ptk::SCAN_BVH;
-    if ((scan == ptk::SCAN_BROAD || scan == ptk::SCAN_VERIFY) && !F.broad_ok)
-        scan = scan == ptk::SCAN_VERIFY ? ptk::SCAN_VERIFY_BVH : ptk::SCAN_BVH;
+    // the LDS copy of the world (objects + materials + record indices) must leave room for five blocks per CU
+    const size_t world_lds = sd.world.size() * sizeof(DevObj) + sd.mats.size() * sizeof(DevMat) + (sd.bsph.size() + sd.bbox.size()) * sizeof(int);
+    const bool wide_ok = F.broad_ok == 2 && world_lds <= 30 * 1024;
+    if (scan < 0) scan = F.broad_ok == 1 ? ptk::SCAN_BROAD : wide_ok ? ptk::SCAN_BROAD_WIDE : ptk::SCAN_BVH;
+    if ((scan == ptk::SCAN_BROAD || scan == ptk::SCAN_VERIFY) && F.broad_ok != 1) {
+        const bool verify = scan == ptk::SCAN_VERIFY;
+        scan = wide_ok ? (verify ? ptk::SCAN_VERIFY_WIDE : ptk::SCAN_BROAD_WIDE) : (verify ? ptk::SCAN_VERIFY_BVH : ptk::SCAN_BVH);
+    }
+    if ((scan == ptk::SCAN_BROAD_WIDE || scan == ptk::SCAN_VERIFY_WIDE) && !wide_ok && F.broad_ok != 1)
+        scan = scan == ptk::SCAN_VERIFY_WIDE ? ptk::SCAN_VERIFY_BVH : ptk::SCAN_BVH;
     sd.scan = scan;
     const bool big = scan == ptk::SCAN_BVH || scan == ptk::SCAN_VERIFY_BVH;
     sd.bvh_nodes.clear();
@@ -859,6 +871,8 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
     if (const char *e = std::getenv("PTCORE_SCAN")) {
         if (!std::strcmp(e, "uniform")) ctx->scan_mode = ptk::SCAN_UNIFORM;
         else if (!std::strcmp(e, "verify")) ctx->scan_mode = ptk::SCAN_VERIFY;
+        else if (!std::strcmp(e, "wide")) ctx->scan_mode = ptk::SCAN_BROAD_WIDE;
+        else if (!std::strcmp(e, "verify_wide")) ctx->scan_mode = ptk::SCAN_VERIFY_WIDE;
         else if (!std::strcmp(e, "bvh")) ctx->scan_mode = ptk::SCAN_BVH;
         else if (!std::strcmp(e, "verify_bvh")) ctx->scan_mode = ptk::SCAN_VERIFY_BVH;
         else ctx->scan_mode = -1;

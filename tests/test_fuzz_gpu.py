@@ -47,7 +47,7 @@ def contexts():
     out = {}
     old = os.environ.get("PTCORE_SCAN")
     try:
-        for mode in ("broad", "bvh", "uniform"):
+        for mode in ("broad", "wide", "bvh", "uniform"):
             os.environ["PTCORE_SCAN"] = mode
             out[mode] = capi.Context(ndev=1)
     finally:
@@ -67,7 +67,7 @@ def test_random_scenes_all_strategies(contexts, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     w, h, spp, depth = 32, 20, 3, 7
     for _ in range(4):
-        doc = _random_doc(rng, int(rng.integers(1, 45)))
+        doc = _random_doc(rng, int(rng.integers(1, 45)) if _ < 3 else int(rng.integers(45, 150)))
         o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=seed + 1)
         sc = scene.Scene.decode(doc)
         for mode, ctx in contexts.items():

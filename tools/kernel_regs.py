@@ -17,7 +17,7 @@ for blk in meta.split("  - .agpr_count:")[1:]:
     name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip()
     name = re.sub(r"\(.*", "", name)
     v = int(g("vgpr_count"))
-    waves = min(8, 512 // max(v, 1)) if v else 8
+    waves = min(8, 512 // max(-(-v // 8) * 8, 8))  # VGPRs are allocated in blocks of 8
     print("%-48s vgpr %3d (<=%d waves/SIMD) sgpr %3s spill v%s s%s lds %6s scratch %s" % (
         name[-48:], v, waves, g("sgpr_count"), g("vgpr_spill_count"), g("sgpr_spill_count"),
         g("group_segment_fixed_size"), g("private_segment_fixed_size")))
