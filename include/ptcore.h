@@ -265,7 +265,7 @@ int32_t pt_debug_profile(pt_ctx *ctx, uint64_t *out, int32_t n);
 int64_t pt_debug_scan_mismatches(pt_ctx *ctx);
 
 /* Diagnostics only, no GPU needed: builds the bounding-volume hierarchy used for scenes with more
- * than 32 spheres or 32 boxes and checks its invariants.  out = {nodes, objects in the tree, depth, most slots
+ * than 128 spheres or 128 boxes and checks its invariants.  out = {nodes, objects in the tree, depth, most slots
  * used by a node (<= 4), objects or nodes not reached exactly once, objects not inside their slot's box,
  * child boxes not inside the parent's box, planes kept outside the tree}. */
 int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]);

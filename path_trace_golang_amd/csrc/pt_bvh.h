@@ -1,4 +1,4 @@
-// pt_bvh.h -- host-side BVH builder for scenes beyond the 32+32-object candidate bitmasks.
+// pt_bvh.h -- host-side BVH builder for scenes beyond the candidate bitmasks (more than 128 spheres or boxes).
 //
 // The reference scans every object for every ray segment (renderer.go:297-302).  Its winner is
 // an order-free function of the per-object hit distances (see `wins` in pt_kernels.h), so any

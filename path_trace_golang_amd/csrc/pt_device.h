@@ -121,7 +121,7 @@ struct DevFrame {
     uint32_t njobs;      // nlocal*16*S*64
     uint32_t claim;      // jobs a wave claims per queue pop (multiple of 64)
     int32_t n_bsph, n_bbox, n_plane;  // broad-phase record counts; planes are always tested exactly
-    int32_t n_bvh_nodes, n_bvh_objs;  // BVH path (scenes beyond 32 spheres / 32 boxes)
+    int32_t n_bvh_nodes, n_bvh_objs;  // BVH path (scenes beyond 128 spheres / 128 boxes)
     int32_t world_in_lds;             // 1: DevObj/DevMat copies are staged in LDS (small scenes)
     int32_t bvh_root;                 // root node of the hierarchy over every finite object, -1 if none
     int32_t bvh_root_exit;            // root of the hierarchy over dielectric objects only, -1 if none

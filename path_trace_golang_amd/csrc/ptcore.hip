@@ -705,7 +705,8 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     F.nobj = (int32_t)sd.world.size();
     F.nmat = (int32_t)sd.mats.size();
     build_broad(sd.world, sd);
-    // closest-hit strategy: at most 32 spheres and 32 boxes -> candidate bitmasks; more -> BVH.  PTCORE_SCAN overrides.
+    // closest-hit strategy: at most 32 spheres and 32 boxes -> candidate bitmasks; at most 128 of each -> the same in
+    // groups of 32; more -> BVH.  PTCORE_SCAN overrides.
     int scan = ctx->scan_mode;
     // the LDS copy of the world (objects + materials + record indices) must leave room for five blocks per CU
     const size_t world_lds = sd.world.size() * sizeof(DevObj) + sd.mats.size() * sizeof(DevMat) + (sd.bsph.size() + sd.bbox.size()) * sizeof(int);

@@ -1,4 +1,4 @@
-"""Scenes with more than 32 spheres or 32 boxes take the BVH path.  The hierarchy only decides
+"""Scenes with more than 128 spheres or 128 boxes take the BVH path, 33-128 the grouped candidate masks.  The hierarchy only decides
 which objects get the exact FP64 test, so the result must equal the reference's linear scan (the oracle)
 exactly: same per-pixel segment/draw counts, same 8-bit image."""
 import numpy as np
@@ -56,7 +56,7 @@ def test_far_cameras_through_the_bvh(gpu_ctx, oracle, cam_scale):
     # hits the geometry does not have; the BVH widens its bounds per ray so that those survive (clip_ray).
     from path_trace_golang_amd import capi, hip, scene, synth
 
-    sc = synth.make_scene(150, 11)
+    sc = synth.make_scene(400, 11)  # more than 128 of a kind: the hierarchy, not the grouped masks
     doc = sc.encode()
     cam = doc["camera"]
     t = cam["target"]
