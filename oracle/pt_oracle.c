@@ -185,7 +185,7 @@ double ora_pow(double x, double y) {
         }
         if (i & 1) { a1 *= x1; ae += xe; }
         x1 *= x1;
-        xe <<= 1;
+        xe *= 2; /* Go: xe <<= 1 (defined for negative values there) */
         if (x1 < .5) { x1 += x1; xe--; }
     }
     return ldexp(a1, ae);
