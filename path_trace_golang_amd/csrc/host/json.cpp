@@ -1,5 +1,7 @@
 #include "json.hpp"
 
+#include <cerrno>
+
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -148,7 +150,8 @@ struct Parser {
             }
             v->kind = Value::Number;
             // strtod is correctly rounded in glibc, like Go's strconv.ParseFloat
-            v->num = std::strtod(s.substr(i, j - i).c_str(), nullptr);
+            v->lit = s.substr(i, j - i);
+            v->num = std::strtod(v->lit.c_str(), nullptr);
             i = j;
         } else {
             fail("unexpected character");
@@ -170,21 +173,63 @@ const Value *Value::get(const std::string &key) const {
     if (found && found->kind == Null) return nullptr;
     return found;
 }
+const char *Value::kind_name(Kind k) {
+    switch (k) {
+        case Null: return "null";
+        case Bool: return "bool";
+        case Number: return "number";
+        case String: return "string";
+        case Array: return "array";
+        default: return "object";
+    }
+}
+
+namespace {
+[[noreturn]] void mismatch(const Value *v, const std::string &key, const char *want) {
+    throw std::runtime_error(std::string("json: cannot unmarshal ") + Value::kind_name(v->kind) + " into field " + key +
+                             " of type " + want);
+}
+}  // namespace
+
 double Value::number(const std::string &key) const {
     const Value *v = get(key);
-    return (v && v->kind == Number) ? v->num : 0.0;
+    if (!v) return 0.0;
+    if (v->kind != Number) mismatch(v, key, "float64");
+    if (std::isinf(v->num)) throw std::runtime_error("json: number " + v->lit + " out of range for field " + key + " of type float64");
+    return v->num;
 }
 long long Value::integer(const std::string &key) const {
     const Value *v = get(key);
-    return (v && v->kind == Number) ? (long long)v->num : 0;
+    if (!v) return 0;
+    if (v->kind != Number) mismatch(v, key, "int");
+    // strconv.ParseInt on the literal: digits with an optional minus sign, nothing else
+    if (v->lit.find_first_of(".eE") != std::string::npos) mismatch(v, key, "int");
+    errno = 0;
+    const long long r = std::strtoll(v->lit.c_str(), nullptr, 10);
+    if (errno == ERANGE) throw std::runtime_error("json: number " + v->lit + " out of range for field " + key + " of type int");
+    return r;
 }
 std::string Value::string(const std::string &key) const {
     const Value *v = get(key);
-    return (v && v->kind == String) ? v->str : std::string();
+    if (!v) return std::string();
+    if (v->kind != String) mismatch(v, key, "string");
+    return v->str;
 }
 bool Value::boolean(const std::string &key) const {
     const Value *v = get(key);
-    return v && v->kind == Bool && v->b;
+    if (!v) return false;
+    if (v->kind != Bool) mismatch(v, key, "bool");
+    return v->b;
+}
+const Value *Value::object(const std::string &key) const {
+    const Value *v = get(key);
+    if (v && v->kind != Object) mismatch(v, key, "struct");
+    return v;
+}
+const Value *Value::array(const std::string &key) const {
+    const Value *v = get(key);
+    if (v && v->kind != Array) mismatch(v, key, "slice");
+    return v;
 }
 
 ValuePtr parse(const std::string &text) {

@@ -18,16 +18,23 @@ struct Value {
     enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
     bool b = false;
     double num = 0.0;
+    std::string lit;   // Number: the literal as written (integer fields take integer literals only, like encoding/json)
     std::string str;
     std::vector<ValuePtr> arr;
     std::vector<std::pair<std::string, ValuePtr>> obj;  // insertion order, duplicate keys kept (last wins on lookup)
 
     // encoding/json field matching: exact key first, else case-insensitive; null counts as absent
     const Value *get(const std::string &key) const;
-    double number(const std::string &key) const;   // 0 when absent / not a number
+    // Typed field reads with json.Unmarshal's rules: absent / null gives the zero value; a value of another JSON
+    // type, a float literal that overflows float64 or a non-integer literal for an int field throws
+    // std::runtime_error ("json: cannot unmarshal ..."), which fails the load like an UnmarshalTypeError.
+    double number(const std::string &key) const;
     long long integer(const std::string &key) const;
     std::string string(const std::string &key) const;
     bool boolean(const std::string &key) const;
+    const Value *object(const std::string &key) const;  // nullptr when absent / null
+    const Value *array(const std::string &key) const;   // nullptr when absent / null
+    static const char *kind_name(Kind k);
 };
 
 // Parses one JSON document (json.Decoder.Decode semantics: trailing data after the first value is ignored).

@@ -48,73 +48,91 @@ std::unique_ptr<Scene> Decode(const std::string &text) {
     }
     if (root->kind != Value::Object) throw std::runtime_error("decode scene: top-level JSON value is not an object");
     auto sc = std::make_unique<Scene>();
-    sc->Name = root->string("name");
-    if (const Value *c = root->get("camera")) {
-        sc->Cam.Position = vec3_of(c->get("position"));
-        sc->Cam.Target = vec3_of(c->get("target"));
-        sc->Cam.Up = vec3_of(c->get("up"));
-        sc->Cam.FOV = c->number("fov");
-        sc->Cam.Aperture = c->number("aperture");
-        sc->Cam.FocusDist = c->number("focus_dist");
-        sc->Cam.AspectRatio = c->number("aspect_ratio");
-    }
-    if (const Value *a = root->get("objects"); a && a->kind == Value::Array) {
-        for (const auto &e : a->arr) {
-            Object o;
-            o.ID = e->string("id");
-            o.Type = e->string("type");
-            o.Position = vec3_of(e->get("position"));
-            o.Size = vec3_of(e->get("size"));
-            o.MaterialID = e->string("material_id");
-            sc->Objects.push_back(o);
+    // every typed read below throws on a value of the wrong JSON type: scene.Load fails on json.Unmarshal's
+    // UnmarshalTypeError the same way (io.go:17-19)
+    try {
+        // a null array element leaves the zero struct; anything but an object is a type error
+        auto element = [](const json::ValuePtr &e, const char *field) -> const Value * {
+            if (e->kind == Value::Null) return nullptr;
+            if (e->kind != Value::Object)
+                throw std::runtime_error(std::string("json: cannot unmarshal ") + Value::kind_name(e->kind) + " into field " + field +
+                                         " of type struct");
+            return e.get();
+        };
+        sc->Name = root->string("name");
+        if (const Value *c = root->object("camera")) {
+            sc->Cam.Position = vec3_of(c->object("position"));
+            sc->Cam.Target = vec3_of(c->object("target"));
+            sc->Cam.Up = vec3_of(c->object("up"));
+            sc->Cam.FOV = c->number("fov");
+            sc->Cam.Aperture = c->number("aperture");
+            sc->Cam.FocusDist = c->number("focus_dist");
+            sc->Cam.AspectRatio = c->number("aspect_ratio");
         }
-    }
-    if (const Value *a = root->get("materials"); a && a->kind == Value::Array) {
-        for (const auto &e : a->arr) {
-            Material m;
-            m.ID = e->string("id");
-            m.Type = e->string("type");
-            m.Albedo = color_of(e->get("albedo"));
-            m.Rough = e->number("rough");
-            m.IOR = e->number("ior");
-            m.Emit = color_of(e->get("emit"));
-            m.Power = e->number("power");
-            m.Absorption = color_of(e->get("absorption"));
-            m.Smoothness = e->number("smoothness");
-            m.Reflectivity = e->number("reflectivity");
-            m.Tint = color_of(e->get("tint"));
-            m.AbsorptionScale = e->number("absorption_scale");
-            sc->Materials.push_back(m);
+        if (const Value *a = root->array("objects")) {
+            for (const auto &el : a->arr) {
+                Object o;
+                if (const Value *e = element(el, "objects")) {
+                    o.ID = e->string("id");
+                    o.Type = e->string("type");
+                    o.Position = vec3_of(e->object("position"));
+                    o.Size = vec3_of(e->object("size"));
+                    o.MaterialID = e->string("material_id");
+                }
+                sc->Objects.push_back(o);
+            }
         }
-    }
-    if (const Value *s = root->get("settings")) {
-        sc->Settings.Width = (int)s->integer("width");
-        sc->Settings.Height = (int)s->integer("height");
-        sc->Settings.SamplesPerPx = (int)s->integer("samples_per_px");
-        sc->Settings.MaxDepth = (int)s->integer("max_depth");
-    }
-    sc->Background = color_of(root->get("background"));
-    if (const Value *s = root->get("sky"); s && s->kind == Value::Object) {
-        sc->SkyPtr = std::make_unique<Sky>();
-        sc->SkyPtr->Type = s->string("type");
-        sc->SkyPtr->Col = color_of(s->get("color"));
-        sc->SkyPtr->Horizon = color_of(s->get("horizon"));
-        sc->SkyPtr->Zenith = color_of(s->get("zenith"));
-    }
-    if (const Value *f = root->get("fog"); f && f->kind == Value::Object) {
-        sc->FogPtr = std::make_unique<Fog>();
-        Fog &g = *sc->FogPtr;
-        g.Density = f->number("density");
-        g.Col = color_of(f->get("color"));
-        g.Scatter = f->number("scatter");
-        g.SigmaS = f->number("sigma_s");
-        g.SigmaA = f->number("sigma_a");
-        g.G = f->number("g");
-        g.HeteroStrength = f->number("hetero_strength");
-        g.NoiseScale = f->number("noise_scale");
-        g.NoiseOctaves = (int)f->integer("noise_octaves");
-        g.AffectSky = f->boolean("affect_sky");
-        g.GPUVolumetric = f->boolean("gpu_volumetric");
+        if (const Value *a = root->array("materials")) {
+            for (const auto &el : a->arr) {
+                Material m;
+                if (const Value *e = element(el, "materials")) {
+                    m.ID = e->string("id");
+                    m.Type = e->string("type");
+                    m.Albedo = color_of(e->object("albedo"));
+                    m.Rough = e->number("rough");
+                    m.IOR = e->number("ior");
+                    m.Emit = color_of(e->object("emit"));
+                    m.Power = e->number("power");
+                    m.Absorption = color_of(e->object("absorption"));
+                    m.Smoothness = e->number("smoothness");
+                    m.Reflectivity = e->number("reflectivity");
+                    m.Tint = color_of(e->object("tint"));
+                    m.AbsorptionScale = e->number("absorption_scale");
+                }
+                sc->Materials.push_back(m);
+            }
+        }
+        if (const Value *s = root->object("settings")) {
+            sc->Settings.Width = (int)s->integer("width");
+            sc->Settings.Height = (int)s->integer("height");
+            sc->Settings.SamplesPerPx = (int)s->integer("samples_per_px");
+            sc->Settings.MaxDepth = (int)s->integer("max_depth");
+        }
+        sc->Background = color_of(root->object("background"));
+        if (const Value *s = root->object("sky")) {
+            sc->SkyPtr = std::make_unique<Sky>();
+            sc->SkyPtr->Type = s->string("type");
+            sc->SkyPtr->Col = color_of(s->object("color"));
+            sc->SkyPtr->Horizon = color_of(s->object("horizon"));
+            sc->SkyPtr->Zenith = color_of(s->object("zenith"));
+        }
+        if (const Value *f = root->object("fog")) {
+            sc->FogPtr = std::make_unique<Fog>();
+            Fog &g = *sc->FogPtr;
+            g.Density = f->number("density");
+            g.Col = color_of(f->object("color"));
+            g.Scatter = f->number("scatter");
+            g.SigmaS = f->number("sigma_s");
+            g.SigmaA = f->number("sigma_a");
+            g.G = f->number("g");
+            g.HeteroStrength = f->number("hetero_strength");
+            g.NoiseScale = f->number("noise_scale");
+            g.NoiseOctaves = (int)f->integer("noise_octaves");
+            g.AffectSky = f->boolean("affect_sky");
+            g.GPUVolumetric = f->boolean("gpu_volumetric");
+        }
+    } catch (const std::exception &e) {
+        throw std::runtime_error(std::string("decode scene: ") + e.what());
     }
     return sc;
 }

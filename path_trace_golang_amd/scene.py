@@ -2,8 +2,10 @@
 
 Types and field names follow /root/reference/internal/scene/scene.go:9-158; `load`
 and `save` follow io.go:10-38.  Decoding behaves like Go's encoding/json into those
-structs: absent keys leave zero values, keys match case-insensitively, `"sky": null`
-(or no "sky") leaves Scene.sky = None, unknown keys are ignored.
+structs: absent keys and nulls leave zero values, keys match case-insensitively, `"sky": null`
+(or no "sky") leaves Scene.sky = None, unknown keys are ignored, and a value of the wrong JSON
+type for its field (or a number that overflows float64) fails the load like json.Unmarshal's
+UnmarshalTypeError does.
 """
 from __future__ import annotations
 
@@ -23,9 +25,18 @@ OBJECT_BOX = "box"
 OBJECT_SPHERE_LIGHT = "sphere_light"
 
 
+def _kind(v) -> str:
+    return ("bool" if isinstance(v, bool) else "number" if isinstance(v, (int, float)) else "string" if isinstance(v, str)
+            else "array" if isinstance(v, list) else "object" if isinstance(v, dict) else type(v).__name__)
+
+
+def _mismatch(v, key: str, want: str):
+    # encoding/json reports the first type mismatch as an UnmarshalTypeError and scene.Load fails with it (io.go:17-19)
+    return ValueError("decode scene: json: cannot unmarshal %s into field %s of type %s" % (_kind(v), key, want))
+
+
 def _get(d, key, default=None):
-    if not isinstance(d, dict):
-        return default
+    """Value of `key` (exact match first, then case-insensitively, like encoding/json); null counts as absent."""
     if key in d:
         v = d[key]
     else:
@@ -39,11 +50,63 @@ def _get(d, key, default=None):
 
 
 def _f(d, key) -> float:
-    return float(_get(d, key, 0.0))
+    v = _get(d, key, 0.0)
+    if isinstance(v, bool) or not isinstance(v, (int, float)):
+        raise _mismatch(v, key, "float64")
+    v = float(v)
+    if v != v or v in (float("inf"), float("-inf")):  # 1e999, or the NaN / Infinity literals Python's parser lets through
+        raise ValueError("decode scene: json: number out of range for field %s of type float64" % key)
+    return v
 
 
 def _i(d, key) -> int:
-    return int(_get(d, key, 0))
+    v = _get(d, key, 0)
+    if isinstance(v, bool) or not isinstance(v, int):  # 1.0 and 1e3 are not integer literals for encoding/json either
+        raise _mismatch(v, key, "int")
+    if not -(1 << 63) <= v < (1 << 63):
+        raise ValueError("decode scene: json: number out of range for field %s of type int" % key)
+    return v
+
+
+def _s(d, key) -> str:
+    v = _get(d, key, "")
+    if not isinstance(v, str):
+        raise _mismatch(v, key, "string")
+    return v
+
+
+def _b(d, key) -> bool:
+    v = _get(d, key, False)
+    if not isinstance(v, bool):
+        raise _mismatch(v, key, "bool")
+    return v
+
+
+def _o(d, key) -> dict:
+    """Nested struct: absent or null gives the zero value (an empty object here)."""
+    v = _get(d, key, None)
+    if v is None:
+        return {}
+    if not isinstance(v, dict):
+        raise _mismatch(v, key, "struct")
+    return v
+
+
+def _a(d, key) -> list:
+    v = _get(d, key, None)
+    if v is None:
+        return []
+    if not isinstance(v, list):
+        raise _mismatch(v, key, "slice")
+    return v
+
+
+def _elem(v, key: str) -> dict:
+    if v is None:  # a null element leaves the zero struct
+        return {}
+    if not isinstance(v, dict):
+        raise _mismatch(v, key, "struct")
+    return v
 
 
 @dataclass
@@ -92,9 +155,8 @@ class Camera:  # scene.go:24-32
 
     @classmethod
     def decode(cls, d) -> "Camera":
-        return cls(Vec3.decode(_get(d, "position", {})), Vec3.decode(_get(d, "target", {})),
-                   Vec3.decode(_get(d, "up", {})), _f(d, "fov"), _f(d, "aperture"), _f(d, "focus_dist"),
-                   _f(d, "aspect_ratio"))
+        return cls(Vec3.decode(_o(d, "position")), Vec3.decode(_o(d, "target")), Vec3.decode(_o(d, "up")), _f(d, "fov"),
+                   _f(d, "aperture"), _f(d, "focus_dist"), _f(d, "aspect_ratio"))
 
     def encode(self) -> dict:
         return {"position": self.position.encode(), "target": self.target.encode(), "up": self.up.encode(),
@@ -119,10 +181,9 @@ class Material:  # scene.go:41-63
 
     @classmethod
     def decode(cls, d) -> "Material":
-        return cls(str(_get(d, "id", "")), str(_get(d, "type", "")), Color.decode(_get(d, "albedo", {})),
-                   _f(d, "rough"), _f(d, "ior"), Color.decode(_get(d, "emit", {})), _f(d, "power"),
-                   Color.decode(_get(d, "absorption", {})), _f(d, "smoothness"), _f(d, "reflectivity"),
-                   Color.decode(_get(d, "tint", {})), _f(d, "absorption_scale"))
+        return cls(_s(d, "id"), _s(d, "type"), Color.decode(_o(d, "albedo")), _f(d, "rough"), _f(d, "ior"),
+                   Color.decode(_o(d, "emit")), _f(d, "power"), Color.decode(_o(d, "absorption")), _f(d, "smoothness"),
+                   _f(d, "reflectivity"), Color.decode(_o(d, "tint")), _f(d, "absorption_scale"))
 
     def encode(self) -> dict:
         return {"id": self.id, "type": self.type, "albedo": self.albedo.encode(), "rough": self.rough,
@@ -142,8 +203,8 @@ class Object:  # scene.go:76-84
 
     @classmethod
     def decode(cls, d) -> "Object":
-        return cls(str(_get(d, "id", "")), str(_get(d, "type", "")), Vec3.decode(_get(d, "position", {})),
-                   Vec3.decode(_get(d, "size", {})), str(_get(d, "material_id", "")))
+        return cls(_s(d, "id"), _s(d, "type"), Vec3.decode(_o(d, "position")), Vec3.decode(_o(d, "size")),
+                   _s(d, "material_id"))
 
     def encode(self) -> dict:
         return {"id": self.id, "type": self.type, "position": self.position.encode(), "size": self.size.encode(),
@@ -182,9 +243,9 @@ class Fog:  # scene.go:96-131 -- carried for round-tripping; the CPU engine igno
 
     @classmethod
     def decode(cls, d) -> "Fog":
-        return cls(_f(d, "density"), Color.decode(_get(d, "color", {})), _f(d, "scatter"), _f(d, "sigma_s"),
-                   _f(d, "sigma_a"), _f(d, "g"), _f(d, "hetero_strength"), _f(d, "noise_scale"),
-                   _i(d, "noise_octaves"), bool(_get(d, "affect_sky", False)), bool(_get(d, "gpu_volumetric", False)))
+        return cls(_f(d, "density"), Color.decode(_o(d, "color")), _f(d, "scatter"), _f(d, "sigma_s"), _f(d, "sigma_a"),
+                   _f(d, "g"), _f(d, "hetero_strength"), _f(d, "noise_scale"), _i(d, "noise_octaves"), _b(d, "affect_sky"),
+                   _b(d, "gpu_volumetric"))
 
     def encode(self) -> dict:
         return {"density": self.density, "color": self.color.encode(), "scatter": self.scatter,
@@ -203,8 +264,7 @@ class Sky:  # scene.go:135-140
 
     @classmethod
     def decode(cls, d) -> "Sky":
-        return cls(str(_get(d, "type", "")), Color.decode(_get(d, "color", {})),
-                   Color.decode(_get(d, "horizon", {})), Color.decode(_get(d, "zenith", {})))
+        return cls(_s(d, "type"), Color.decode(_o(d, "color")), Color.decode(_o(d, "horizon")), Color.decode(_o(d, "zenith")))
 
     def encode(self) -> dict:
         return {"type": self.type, "color": self.color.encode(), "horizon": self.horizon.encode(),
@@ -226,14 +286,14 @@ class Scene:  # scene.go:143-158
     def decode(cls, doc: dict) -> "Scene":
         if not isinstance(doc, dict):
             raise ValueError("decode scene: top-level JSON value is not an object")
-        sky = _get(doc, "sky", None)
+        sky = _get(doc, "sky", None)  # *Sky / *Fog: null or absent leaves the nil pointer
         fog = _get(doc, "fog", None)
-        return cls(str(_get(doc, "name", "")), Camera.decode(_get(doc, "camera", {})),
-                   [Object.decode(o) for o in (_get(doc, "objects", []) or [])],
-                   [Material.decode(m) for m in (_get(doc, "materials", []) or [])],
-                   RenderSettings.decode(_get(doc, "settings", {})), Color.decode(_get(doc, "background", {})),
-                   Sky.decode(sky) if isinstance(sky, dict) else None,
-                   Fog.decode(fog) if isinstance(fog, dict) else None)
+        return cls(_s(doc, "name"), Camera.decode(_o(doc, "camera")),
+                   [Object.decode(_elem(o, "objects")) for o in _a(doc, "objects")],
+                   [Material.decode(_elem(m, "materials")) for m in _a(doc, "materials")],
+                   RenderSettings.decode(_o(doc, "settings")), Color.decode(_o(doc, "background")),
+                   Sky.decode(_o(doc, "sky")) if sky is not None else None,
+                   Fog.decode(_o(doc, "fog")) if fog is not None else None)
 
     def encode(self) -> dict:
         d = {"name": self.name, "camera": self.camera.encode(), "objects": [o.encode() for o in self.objects],

@@ -162,3 +162,72 @@ def test_cli_flag_surface(host):
     assert "headless render error: load scene: open scene" in r.stderr
     r = _cli()  # no -headless: the reference would open the UI
     assert r.returncode == 1 and "ui error" in r.stderr
+
+
+def test_json_decoder_survives_mutated_input(host):
+    # 3000 mutations of the scene files (truncation, byte flips, deep nesting, huge numbers): the C++ decoder must
+    # return a scene or an error, never crash; whatever it accepts must flatten and re-encode
+    import ctypes as C
+    import random
+
+    lib = host
+    rnd = random.Random(4242)
+    texts = [open(scene_path(n), "rb").read() for n in SCENE_NAMES]
+    extra = [b"", b"{", b"[" * 5000, b"{\"objects\":" + b"[" * 3000, b"{\"camera\":{\"fov\":1e999}}", b"{\"objects\":[{\"type\":7}]}",
+             b"\"\\ud800\"", b"{\"materials\":[{\"id\":\"" + b"x" * 100000 + b"\"}]}", b"nul", b"{\"a\":1,}", b"\xff\xfe{}"]
+    accepted = 0
+    for i in range(3000):
+        if i < len(extra):
+            t = extra[i]
+        else:
+            t = bytearray(rnd.choice(texts))
+            for _ in range(rnd.randint(1, 6)):
+                op = rnd.random()
+                pos = rnd.randrange(len(t)) if t else 0
+                if op < 0.3 and t:
+                    t[pos] = rnd.randrange(256)
+                elif op < 0.5:
+                    del t[pos:pos + rnd.randint(1, 40)]
+                elif op < 0.7:
+                    t[pos:pos] = rnd.choice([b"{", b"}", b"[", b"]", b",", b":", b"\"", b"-", b"1e400", b"\\u12", b"null", b"\x00"])
+                elif op < 0.8:
+                    t = t[:pos]
+                else:
+                    t[pos:pos] = t[max(0, pos - 30):pos]
+            t = bytes(t)
+        h = lib.pth_scene_decode(t.replace(b"\x00", b" "))
+        if h:
+            accepted += 1
+            flat = lib.pth_scene_flat(h)
+            assert flat
+            enc = lib.pth_scene_encode(h)
+            assert enc is not None
+            lib.pth_scene_free(h)
+        else:
+            assert lib.pth_last_error()
+    assert accepted > 100  # many mutations only touch numbers or unknown keys
+
+
+BAD_TYPES = ['{"objects":[{"type":7}]}', '{"camera":{"fov":"x"}}', '{"camera":{"fov":1e999}}', '{"objects":{}}',
+             '{"materials":[{"id":5}]}', '{"camera":{"position":[1,2,3]}}', '{"settings":{"width":1.0}}',
+             '{"settings":{"width":1e3}}', '{"settings":{"width":true}}', '{"camera":{"fov":true}}', '{"sky":5}',
+             '{"fog":{"affect_sky":1}}', '{"objects":[3]}', '{"name":[]}', '{"background":"red"}']
+GOOD_TYPES = ['{"sky":null,"objects":null,"camera":null,"name":null,"settings":null}', '{"objects":[null]}',
+              '{"junk":1e999,"camera":{"FOV":2,"extra":[1,"a"]}}', '{"settings":{"width":-3}}', '{"camera":{"fov":1e-999}}']
+
+
+def test_type_mismatches_fail_the_load_like_json_unmarshal(host):
+    # encoding/json reports a value of the wrong JSON type (or a float literal out of range) as an error and
+    # scene.Load fails (io.go:17-19); null and unknown keys are fine.  Same in the C++ and the Python decoder.
+    from path_trace_golang_amd import scene
+
+    for t in BAD_TYPES:
+        assert not host.pth_scene_decode(t.encode()), t
+        assert b"decode scene: json:" in host.pth_last_error(), (t, host.pth_last_error())
+        with pytest.raises(ValueError, match="decode scene: json:"):
+            scene.Scene.decode(json.loads(t))
+    for t in GOOD_TYPES:
+        h = host.pth_scene_decode(t.encode())
+        assert h, (t, host.pth_last_error())
+        host.pth_scene_free(h)
+        scene.Scene.decode(json.loads(t))
