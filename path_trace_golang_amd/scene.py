@@ -311,10 +311,12 @@ def load(path: str) -> Scene:
     except OSError as e:
         raise OSError("open scene: %s" % e) from e
     with f:
-        try:
-            doc = json.load(f)
-        except json.JSONDecodeError as e:
-            raise ValueError("decode scene: %s" % e) from e
+        text = f.read()
+    try:
+        # json.Decoder.Decode reads ONE value and leaves whatever follows it unread (io.go:17)
+        doc, _ = json.JSONDecoder().raw_decode(text.lstrip(" \t\r\n"))
+    except json.JSONDecodeError as e:
+        raise ValueError("decode scene: %s" % e) from e
     return Scene.decode(doc)
 
 

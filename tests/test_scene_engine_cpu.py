@@ -105,3 +105,16 @@ def test_save_png(tmp_path):
     assert back.shape == (4, 6, 4) and np.array_equal(back, img)
     with pytest.raises(OSError, match="create png"):
         engine.save_png(str(tmp_path / "nodir" / "o.png"), img)
+
+
+def test_load_reads_one_json_value_like_the_go_decoder(tmp_path):
+    # scene.Load uses json.NewDecoder(f).Decode: data after the first value is not looked at (io.go:17)
+    from path_trace_golang_amd import scene
+
+    p = tmp_path / "s.json"
+    p.write_text('  {"name": "n", "camera": {"fov": 33}}\n{"name": "second"} trailing')
+    sc = scene.load(str(p))
+    assert sc.name == "n" and sc.camera.fov == 33
+    p.write_text("")
+    with pytest.raises(ValueError, match="decode scene"):
+        scene.load(str(p))
