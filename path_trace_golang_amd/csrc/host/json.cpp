@@ -1,6 +1,7 @@
 #include "json.hpp"
 
 #include <cerrno>
+#include <cstdint>
 
 #include <cctype>
 #include <cmath>
@@ -256,7 +257,10 @@ std::string format_number(double v) {
         }
         s = buf;
     } else if (s.find('e') != std::string::npos) {
-        // Go writes e-07 as e-07 and e+21 as e+21 (two exponent digits minimum), same as C
+        // strconv's 'e' layout pads the exponent to two digits like C; encoding/json then cleans up e-09 to e-9
+        // (encode.go floatEncoder) and leaves e+21 alone
+        const size_t n = s.size();
+        if (n >= 4 && s[n - 4] == 'e' && s[n - 3] == '-' && s[n - 2] == '0') s.erase(n - 2, 1);
     }
     return s;
 }
@@ -284,21 +288,54 @@ void Writer::end_array() {
     if (n > 0) { out_ += "\n"; out_.append(2 * counts_.size(), ' '); }
     out_ += "]";
 }
+// String escaping of encoding/json (encode.go, with the Encoder's default HTML escaping): ", \\, \b, \f, \n, \r, \t;
+// other control characters, <, >, & and U+2028 / U+2029 as \u00xx / \u20xx; invalid UTF-8 becomes \ufffd.
 void Writer::raw_string(const std::string &v) {
     out_ += '"';
-    for (unsigned char c : v) {
-        switch (c) {
-            case '"': out_ += "\\\""; break;
-            case '\\': out_ += "\\\\"; break;
-            case '\n': out_ += "\\n"; break;
-            case '\r': out_ += "\\r"; break;
-            case '\t': out_ += "\\t"; break;
-            case '<': out_ += "\\u003c"; break;  // encoding/json escapes HTML-sensitive characters by default
-            case '>': out_ += "\\u003e"; break;
-            case '&': out_ += "\\u0026"; break;
-            default:
-                if (c < 0x20) { char b[8]; std::snprintf(b, sizeof b, "\\u%04x", c); out_ += b; }
-                else out_ += (char)c;
+    const size_t n = v.size();
+    for (size_t i = 0; i < n;) {
+        const unsigned char c = (unsigned char)v[i];
+        if (c < 0x80) {
+            switch (c) {
+                case '"': out_ += "\\\""; break;
+                case '\\': out_ += "\\\\"; break;
+                case '\b': out_ += "\\b"; break;
+                case '\f': out_ += "\\f"; break;
+                case '\n': out_ += "\\n"; break;
+                case '\r': out_ += "\\r"; break;
+                case '\t': out_ += "\\t"; break;
+                case '<': out_ += "\\u003c"; break;
+                case '>': out_ += "\\u003e"; break;
+                case '&': out_ += "\\u0026"; break;
+                default:
+                    if (c < 0x20) { char b[8]; std::snprintf(b, sizeof b, "\\u%04x", c); out_ += b; }
+                    else out_ += (char)c;
+            }
+            i++;
+            continue;
+        }
+        // multi-byte sequence: length, continuation bytes, no overlong forms, no surrogates, <= U+10FFFF
+        int len = (c >= 0xf0) ? 4 : (c >= 0xe0) ? 3 : (c >= 0xc2) ? 2 : 0;
+        uint32_t cp = 0;
+        bool ok = len != 0 && c <= 0xf4 && i + (size_t)len <= n;
+        if (ok) {
+            cp = c & (0xffu >> (len + 1));
+            for (int k = 1; k < len; k++) {
+                const unsigned char d = (unsigned char)v[i + (size_t)k];
+                if ((d & 0xc0) != 0x80) { ok = false; break; }
+                cp = (cp << 6) | (d & 0x3fu);
+            }
+            if (ok && ((len == 3 && cp < 0x800) || (len == 4 && cp < 0x10000) || (cp >= 0xd800 && cp <= 0xdfff) || cp > 0x10ffff)) ok = false;
+        }
+        if (!ok) {
+            out_ += "\\ufffd";
+            i++;
+        } else if (cp == 0x2028 || cp == 0x2029) {
+            out_ += cp == 0x2028 ? "\\u2028" : "\\u2029";
+            i += (size_t)len;
+        } else {
+            out_.append(v, i, (size_t)len);
+            i += (size_t)len;
         }
     }
     out_ += '"';

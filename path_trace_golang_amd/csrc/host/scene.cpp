@@ -70,6 +70,7 @@ std::unique_ptr<Scene> Decode(const std::string &text) {
             sc->Cam.AspectRatio = c->number("aspect_ratio");
         }
         if (const Value *a = root->array("objects")) {
+            sc->ObjectsNil = false;
             for (const auto &el : a->arr) {
                 Object o;
                 if (const Value *e = element(el, "objects")) {
@@ -83,6 +84,7 @@ std::unique_ptr<Scene> Decode(const std::string &text) {
             }
         }
         if (const Value *a = root->array("materials")) {
+            sc->MaterialsNil = false;
             for (const auto &el : a->arr) {
                 Material m;
                 if (const Value *e = element(el, "materials")) {
@@ -157,7 +159,9 @@ std::string Encode(const Scene &sc) {
         w.key("focus_dist"); w.value(sc.Cam.FocusDist);
         w.key("aspect_ratio"); w.value(sc.Cam.AspectRatio);
         w.end_object();
-        w.key("objects"); w.begin_array();
+        w.key("objects");
+        if (sc.ObjectsNil && sc.Objects.empty()) w.null(); else {
+        w.begin_array();
         for (const Object &o : sc.Objects) {
             w.begin_object();
             w.key("id"); w.value(o.ID);
@@ -167,7 +171,10 @@ std::string Encode(const Scene &sc) {
             w.end_object();
         }
         w.end_array();
-        w.key("materials"); w.begin_array();
+        }
+        w.key("materials");
+        if (sc.MaterialsNil && sc.Materials.empty()) w.null(); else {
+        w.begin_array();
         for (const Material &m : sc.Materials) {
             w.begin_object();
             w.key("id"); w.value(m.ID);
@@ -185,6 +192,7 @@ std::string Encode(const Scene &sc) {
             w.end_object();
         }
         w.end_array();
+        }
         w.key("settings"); w.begin_object();
         w.key("width"); w.value((long long)sc.Settings.Width);
         w.key("height"); w.value((long long)sc.Settings.Height);

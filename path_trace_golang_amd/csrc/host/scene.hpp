@@ -70,6 +70,8 @@ struct Scene {  // scene.go:143-158
     Camera Cam;
     std::vector<Object> Objects;
     std::vector<Material> Materials;
+    // Go distinguishes a nil slice (no "objects" key, or null: Save writes null) from an empty one (Save writes [])
+    bool ObjectsNil = true, MaterialsNil = true;
     RenderSettings Settings;
     Color Background;
     std::unique_ptr<Sky> SkyPtr;  // nil when absent or null

@@ -281,6 +281,9 @@ class Scene:  # scene.go:143-158
     background: Color = field(default_factory=Color)
     sky: Optional[Sky] = None
     fog: Optional[Fog] = None
+    # Go distinguishes a nil slice (no key, or null: Save writes null) from an empty one (Save writes [])
+    objects_nil: bool = field(default=True, compare=False)
+    materials_nil: bool = field(default=True, compare=False)
 
     @classmethod
     def decode(cls, doc: dict) -> "Scene":
@@ -293,11 +296,14 @@ class Scene:  # scene.go:143-158
                    [Material.decode(_elem(m, "materials")) for m in _a(doc, "materials")],
                    RenderSettings.decode(_o(doc, "settings")), Color.decode(_o(doc, "background")),
                    Sky.decode(_o(doc, "sky")) if sky is not None else None,
-                   Fog.decode(_o(doc, "fog")) if fog is not None else None)
+                   Fog.decode(_o(doc, "fog")) if fog is not None else None,
+                   _get(doc, "objects", None) is None, _get(doc, "materials", None) is None)
 
     def encode(self) -> dict:
-        d = {"name": self.name, "camera": self.camera.encode(), "objects": [o.encode() for o in self.objects],
-             "materials": [m.encode() for m in self.materials], "settings": self.settings.encode(),
+        d = {"name": self.name, "camera": self.camera.encode(),
+             "objects": None if (self.objects_nil and not self.objects) else [o.encode() for o in self.objects],
+             "materials": None if (self.materials_nil and not self.materials) else [m.encode() for m in self.materials],
+             "settings": self.settings.encode(),
              "background": self.background.encode(), "sky": self.sky.encode() if self.sky is not None else None}
         if self.fog is not None:  # `json:"fog,omitempty"`
             d["fog"] = self.fog.encode()
@@ -327,5 +333,66 @@ def save(path: str, sc: Scene) -> None:
     except OSError as e:
         raise OSError("create scene: %s" % e) from e
     with f:
-        json.dump(sc.encode(), f, indent=2, ensure_ascii=False)
-        f.write("\n")
+        f.write(dumps(sc))
+
+
+def _go_float(f: float) -> str:
+    """encoding/json's float64 formatting (encode.go floatEncoder): shortest digits that round-trip, 'f' layout
+    unless |f| < 1e-6 or |f| >= 1e21, then 'e' layout with a one-digit negative exponent cleaned up (e-07 -> e-7)."""
+    import math
+    from decimal import Decimal
+
+    if math.isnan(f) or math.isinf(f):
+        raise ValueError("encode scene: json: unsupported value: %r" % f)
+    if f == 0:
+        return "-0" if math.copysign(1.0, f) < 0 else "0"
+    a = abs(f)
+    d = Decimal(repr(float(f)))  # repr gives the shortest round-trip digits, like strconv's -1 precision
+    if a < 1e-6 or a >= 1e21:
+        sign, digits, exp = d.as_tuple()
+        digs = "".join(map(str, digits)).rstrip("0") or "0"
+        e10 = exp + len(digits) - 1
+        mant = digs[0] + ("." + digs[1:] if len(digs) > 1 else "")
+        es = "%s%02d" % ("-" if e10 < 0 else "+", abs(e10))
+        if e10 < 0 and abs(e10) < 10:
+            es = "-%d" % abs(e10)
+        return ("-" if sign else "") + mant + "e" + es
+    s = format(d, "f")
+    if "." in s:
+        s = s.rstrip("0").rstrip(".")
+    return s
+
+
+def _go_string(v: str) -> str:
+    text = json.dumps(v, ensure_ascii=False)  # ", \\, \b, \f, \n, \r, \t and \u00xx like encoding/json
+    for ch, esc in (("<", "\\u003c"), (">", "\\u003e"), ("&", "\\u0026"), ("\u2028", "\\u2028"), ("\u2029", "\\u2029"),
+                    ("\x7f", "\x7f")):
+        text = text.replace(ch, esc)
+    return text
+
+
+def _go_value(v, level: int) -> str:
+    pad, pad_in = "  " * level, "  " * (level + 1)
+    if v is None:
+        return "null"
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, int):
+        return str(v)
+    if isinstance(v, float):
+        return _go_float(v)
+    if isinstance(v, str):
+        return _go_string(v)
+    if isinstance(v, list):
+        if not v:
+            return "[]"
+        return "[\n" + ",\n".join(pad_in + _go_value(e, level + 1) for e in v) + "\n" + pad + "]"
+    if not v:
+        return "{}"
+    return "{\n" + ",\n".join(pad_in + _go_string(k) + ": " + _go_value(e, level + 1) for k, e in v.items()) + "\n" + pad + "}"
+
+
+def dumps(sc: Scene) -> str:
+    """The text scene.Save writes (io.go:25-38): json.Encoder with SetIndent("", "  "), its float and string
+    formatting (HTML escaping on), a trailing newline."""
+    return _go_value(sc.encode(), 0) + "\n"

@@ -231,3 +231,39 @@ def test_type_mismatches_fail_the_load_like_json_unmarshal(host):
         assert h, (t, host.pth_last_error())
         host.pth_scene_free(h)
         scene.Scene.decode(json.loads(t))
+
+
+def test_save_text_is_encoding_json_text_in_both_mirrors(host):
+    # scene.Save (io.go:25-38) = json.Encoder with SetIndent("", "  "): ES6-style floats (exponent form below 1e-6 and
+    # from 1e21, "e-7" not "e-07", integers without ".0", "-0"), HTML escaping, nil slices as null.  The C++ and the
+    # Python writer must produce the same bytes; known spellings are checked literally.
+    from path_trace_golang_amd import scene
+
+    vals = {0.0: "0", 1.0: "1", 0.1: "0.1", 1e-6: "0.000001", 1e-7: "1e-7", 9.5e-10: "9.5e-10", 1.5e-12: "1.5e-12",
+            1e20: "100000000000000000000", 1e21: "1e+21", 2.5e21: "2.5e+21", 1e100: "1e+100", 5e-324: "5e-324",
+            123456789.125: "123456789.125", -0.9520649081431036: "-0.9520649081431036",
+            1.7976931348623157e308: "1.7976931348623157e+308"}
+    name = "a<b>&c" + chr(0x2028) + chr(8) + chr(12) + chr(1) + chr(0xe9) + '"' + chr(92)
+    doc = {"name": name, "objects": [], "materials": [{"id": "m%d" % i, "rough": v} for i, v in enumerate(vals)]}
+    text = json.dumps(doc)
+    h = host.pth_scene_decode(text.encode())
+    assert h, host.pth_last_error()
+    cpp = host.pth_scene_encode(h).decode()
+    host.pth_scene_free(h)
+    py = scene.dumps(scene.Scene.decode(json.loads(text)))
+    assert cpp == py
+    for v, want in vals.items():
+        assert '"rough": %s,' % want in cpp, (v, want)
+    want_name = '"name": "a' + chr(92) + 'u003cb' + chr(92) + 'u003e' + chr(92) + 'u0026c' + chr(92) + 'u2028' + chr(92) + 'b' + \
+                chr(92) + 'f' + chr(92) + 'u0001' + chr(0xe9) + chr(92) + '"' + chr(92) + chr(92) + '",'
+    assert want_name in cpp
+    assert '"objects": [],' in cpp and cpp.endswith("}\n")
+    h = host.pth_scene_decode(b'{"camera":{"fov":-0.0}}')
+    enc = host.pth_scene_encode(h).decode()
+    assert '"objects": null,\n  "materials": null,' in enc and '"fov": -0,' in enc
+    host.pth_scene_free(h)
+    for n in SCENE_NAMES:  # the reference's own files through both writers
+        raw = open(scene_path(n)).read()
+        h = host.pth_scene_decode(raw.encode())
+        assert host.pth_scene_encode(h).decode() == scene.dumps(scene.Scene.decode(json.loads(raw)))
+        host.pth_scene_free(h)
