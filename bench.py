@@ -83,10 +83,9 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if args.gpus > 1:
-            print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                  % (args.gpus, args.gpus), file=sys.stderr)
-            return 2
+        print("bench.py --gpus %d was launched with WORLD_SIZE=%d: start it with torch.distributed.run "
+              "--nproc-per-node %d (or plainly for --gpus 1)" % (args.gpus, world, args.gpus), file=sys.stderr)
+        return 2
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: torch.cuda.is_available() is False", file=sys.stderr)
         return 2
@@ -125,15 +124,17 @@ def main() -> int:
     frame = None
     packed = None
     if rank == 0:
-        scratch = [torch.empty_like(tiles) for _ in range(world)] if world > 1 else None
+        # the gather lands straight in one contiguous buffer (shard k at k * stride_tiles tiles): no copy before the untile
         packed = torch.empty(world * stride_tiles * 4096, dtype=torch.uint8, device=dev) if world > 1 else None
+        scratch = list(packed.split(stride_tiles * 4096)) if world > 1 else None
         frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
 
     def untile(bufs, stride):
         src = bufs[0]
         if len(bufs) > 1:
-            torch.cat(bufs, out=packed)
+            if bufs[0].data_ptr() != packed.data_ptr():  # rehearsal path: the buffers came through host memory
+                torch.cat(bufs, out=packed)
             src = packed
         capi.check(L.pt_untile_device(ctx.handle, W, H, world, stride, C.c_void_p(src.data_ptr()), None,
                                       C.c_void_p(frame.data_ptr()), W * 4, None, C.c_void_p(stream.cuda_stream)))
@@ -198,6 +199,7 @@ def main() -> int:
         alg_bytes = (58.0 + 24.0) * jobs_per_launch
         achieved_gbs = alg_bytes / max(avg_launch_s, 1e-12) / 1e9
         traffic = None
+        traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_cfg = (world == 1 and args.scene == "gpu_showcase" and (W, H, args.spp, args.depth) == (1920, 1080, 1024, 8)
                        and args.spp_chunk == 0)
@@ -207,6 +209,9 @@ def main() -> int:
                     tk = json.load(f).get("trace_kernel", {})
                 # PMC bytes per sample of a full-chunk launch x the samples of this run's average launch
                 traffic = tk["hbm_bytes_per_sample"] * jobs_per_launch if tk.get("hbm_bytes_per_sample") else None
+                if traffic is not None:
+                    traffic_source = ("NOT measured in this run: %.2f B/sample from profiles/pmc_traffic.json [%s] x this run's "
+                                      "samples per launch" % (tk["hbm_bytes_per_sample"], tk.get("source", "?")))
             except Exception:
                 traffic = None
         objs = [o.type for o in sc.objects]
@@ -239,14 +244,17 @@ def main() -> int:
             "segments_per_sample": segments / max(samples, 1.0),
             "exit_scans_per_segment": exits / max(segments, 1.0),
             "pixel_rmse_vs_cpu_ref": None,
+            "timed_region": "K whole frames: 5 KB scene upload, ray generation, trace, resolve, tile gather (N > 1) and untile; "
+                            "the RGBA8 frame stays in HBM on rank 0, its 8.3 MB D2H copy (~0.2 ms) is excluded",
             "roofline": {"bound": "hbm", "kernel": "ptk::trace_kernel<false,false,1>", "achieved": achieved_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "alg_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "traffic_source": traffic_source, "alg_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": n_launch / steps,
                          "note": "register-resident paths: HBM carries 82 B per SAMPLE (primary ray in, radiance "
                                  "out), nothing per bounce; the binding resource is VALU issue, see roofline_fp64"},
             "roofline_fp64": {"bound": "fp64_valu", "achieved": fp64_tops, "peak": FP64_PEAK_NOFMA_TOPS,
                               "unit": "Tflop/s (unfused)", "frac": fp64_tops / FP64_PEAK_NOFMA_TOPS,
+                              "frac_of_fma_peak": fp64_tops / (2.0 * FP64_PEAK_NOFMA_TOPS),
                               "alg_flops_per_segment": fseg,
                               "trace_share_of_step": trace_ms / max(elapsed * 1e3, 1e-9),
                               "raygen_ms_per_step": sum(s.raygen_ms for s in stats) / steps,

@@ -2,7 +2,8 @@
 // tag, so the binary needs only libc and libptcore.so.  NOT COMPILED IN THE BUILD IMAGE (no Go).
 //
 // Reference flags kept verbatim: -scene -mode -gpu -headless -out.
-// Additive flags: -width -height -spp -depth (override the mode preset), -seed, -devices.
+// Additive flags: -width -height -spp -depth (override the mode preset), -seed, -devices,
+// -scene-settings (the editor's scene-settings override, internal/ui/app.go:60-75; off = main.go:52).
 package main
 
 import (
@@ -29,6 +30,7 @@ func main() {
 	depth := flag.Int("depth", -1, "max path depth (default: the mode preset)")
 	seed := flag.Uint64("seed", 1, "sample-stream seed")
 	devices := flag.Int("devices", 1, "number of GPUs to tile the image over")
+	sceneSettings := flag.Bool("scene-settings", false, "let the scene file's settings block override the mode preset")
 	flag.Parse()
 	log.Printf("flags: scene=%s mode=%s headless=%v out=%s\n", *scenePath, *mode, *headless, *output)
 
@@ -49,6 +51,21 @@ func main() {
 		os.Exit(1)
 	}
 	s := engine.RenderSettingsForMode(*mode)
+	if *sceneSettings { // internal/ui/app.go:60-75
+		if sc.Settings.Width > 0 && sc.Settings.Height > 0 {
+			s.Width, s.Height = sc.Settings.Width, sc.Settings.Height
+			if sc.Settings.SamplesPerPx > 0 {
+				s.SamplesPerPx = sc.Settings.SamplesPerPx
+			}
+			if sc.Settings.MaxDepth > 0 {
+				s.MaxDepth = sc.Settings.MaxDepth
+			}
+		}
+		if *mode == "final" {
+			s.SamplesPerPx *= 4
+			s.MaxDepth *= 2
+		}
+	}
 	if *width > 0 {
 		s.Width = *width
 	}

@@ -44,7 +44,8 @@ def _run(cmd: list[str]) -> None:
 
 def build_core(force: bool = False) -> str:
     out = os.path.join(PKG, "libptcore.so")
-    srcs = [os.path.join(CSRC, f) for f in ("ptcore.hip", "pt_kernels.h", "pt_device.h", "pt_math.h")]
+    # every header and kernel source next to ptcore.hip (pt_kernels.h, pt_device.h, pt_math.h, pt_bvh.h, ...)
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(ROOT, "include", "ptcore.h"))
     if force or _newer(out, srcs):
         _run([HIPCC, *HIP_FLAGS, "-shared", os.path.join(CSRC, "ptcore.hip"), "-o", out])

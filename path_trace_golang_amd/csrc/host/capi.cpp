@@ -90,6 +90,12 @@ void pth_settings_for_mode(const char *mode, int32_t out[4]) {
     out[0] = s.Width; out[1] = s.Height; out[2] = s.SamplesPerPx; out[3] = s.MaxDepth;
 }
 
+// internal/ui/app.go:60-75 (what the CLI twin applies under -scene-settings)
+void pth_settings_for_scene(void *h, const char *mode, int32_t out[4]) {
+    auto s = pthost::engine::RenderSettingsForScene(*static_cast<Handle *>(h)->sc, mode);
+    out[0] = s.Width; out[1] = s.Height; out[2] = s.SamplesPerPx; out[3] = s.MaxDepth;
+}
+
 // engine.RenderInto into caller memory; progress may be NULL. Returns 0 or 1 (pth_last_error()).
 int pth_render_into(void *h, int32_t width, int32_t height, int32_t spp, int32_t depth, uint64_t seed, uint8_t *pix,
                     int32_t img_width, int32_t img_height, int32_t stride, void (*progress)(void)) {

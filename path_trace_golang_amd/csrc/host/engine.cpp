@@ -297,6 +297,21 @@ scene::RenderSettings RenderSettingsForMode(const std::string &mode) {
     return s;
 }
 
+scene::RenderSettings RenderSettingsForScene(const scene::Scene &sc, const std::string &mode) {
+    scene::RenderSettings s = RenderSettingsForMode(mode);  // baseSettings, app.go:60
+    if (sc.Settings.Width > 0 && sc.Settings.Height > 0) {  // app.go:61-70
+        s.Width = sc.Settings.Width;
+        s.Height = sc.Settings.Height;
+        if (sc.Settings.SamplesPerPx > 0) s.SamplesPerPx = sc.Settings.SamplesPerPx;
+        if (sc.Settings.MaxDepth > 0) s.MaxDepth = sc.Settings.MaxDepth;
+    }
+    if (mode == "final") {  // finalSettings, app.go:72-75
+        s.SamplesPerPx *= 4;
+        s.MaxDepth *= 2;
+    }
+    return s;
+}
+
 void SavePNG(const std::string &path, const RGBA &img) {
     std::ofstream f(path, std::ios::binary | std::ios::trunc);
     if (!f) throw std::runtime_error("create png: open " + path + ": " + std::strerror(errno));

@@ -52,6 +52,11 @@ void RenderInto(const scene::Scene &sc, const RenderConfig &cfg, RGBA &img, cons
 RGBA Render(const scene::Scene &sc, const RenderConfig &cfg);                       // renderer.go:25-29
 RGBA RenderScene(const scene::Scene &sc, const scene::RenderSettings &settings, uint64_t seed = 1);  // util.go:13-22
 scene::RenderSettings RenderSettingsForMode(const std::string &mode);               // util.go:25-42
+// The editor's "scene settings override" (internal/ui/app.go:60-75): the mode preset, replaced by the scene's own
+// width x height when BOTH are > 0 (and, only then, by its samples_per_px / max_depth when > 0); a "final" render
+// then takes four times the samples and twice the depth (app.go:72-75).  cmd/render ignores scene.settings
+// (main.go:52); the CLI twin applies this rule only under -scene-settings.
+scene::RenderSettings RenderSettingsForScene(const scene::Scene &sc, const std::string &mode);
 void SavePNG(const std::string &path, const RGBA &img);                             // util.go:45-55; throws "create png: ..."
 
 }  // namespace engine

@@ -5,7 +5,9 @@
 //
 // Additive flags (the reference CLI cannot express the benchmark configurations, main.go:52 and
 // util.go:25-42 hard-wire two presets): -width -height -spp -depth override the mode preset,
-// -seed selects the sample streams (also env PATHTRACER_SEED), -devices N uses N GPUs (0..N-1).
+// -seed selects the sample streams (also env PATHTRACER_SEED), -devices N uses N GPUs (0..N-1),
+// -scene-settings applies the editor's scene-settings override (internal/ui/app.go:60-75) before them;
+// without it scene.settings is ignored exactly as main.go:52 does.
 #include <cerrno>
 #include <chrono>
 #include <cstdarg>
@@ -42,6 +44,7 @@ struct Flags {
     std::string mode = "preview";
     bool gpu = false;
     bool headless = false;
+    bool scene_settings = false;
     std::string out = "output.png";
     int width = 0, height = 0, spp = -1, depth = -1, devices = 1;
     unsigned long long seed = 1;
@@ -58,6 +61,7 @@ void usage() {
                  "  -mode string\n    \trender mode: preview or final (default \"preview\")\n"
                  "  -out string\n    \toutput PNG file for headless render (default \"output.png\")\n"
                  "  -scene string\n    \tpath to scene JSON file (default \"scenes/example_simple.json\")\n"
+                 "  -scene-settings\n    \tlet the scene file's settings block override the mode preset (the editor's rule)\n"
                  "  -seed uint\n    \tsample-stream seed (default 1, or PATHTRACER_SEED)\n"
                  "  -spp int\n    \tsamples per pixel (default: the mode preset)\n"
                  "  -width int\n    \timage width (default: the mode preset)\n");
@@ -81,14 +85,14 @@ int parse(int argc, char **argv, Flags &f) {
         size_t eq = name.find('=');
         if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); has_val = true; }
         if (name == "h" || name == "help") { usage(); return 0; }
-        if (name == "gpu" || name == "headless") {
+        if (name == "gpu" || name == "headless" || name == "scene-settings") {
             bool b = true;
             if (has_val && !parse_bool(val, b)) {
                 std::fprintf(stderr, "invalid boolean value \"%s\" for -%s: parse error\n", val.c_str(), name.c_str());
                 usage();
                 return 2;
             }
-            (name == "gpu" ? f.gpu : f.headless) = b;
+            (name == "gpu" ? f.gpu : name == "headless" ? f.headless : f.scene_settings) = b;
             continue;
         }
         static const char *known[] = {"scene", "mode", "out", "width", "height", "spp", "depth", "seed", "devices"};
@@ -139,7 +143,8 @@ int render_headless(const Flags &f) {
         logf("headless render error: load scene: %s", e.what());
         return 1;
     }
-    scene::RenderSettings s = engine::RenderSettingsForMode(f.mode);  // scene.settings is ignored, like main.go:52
+    // scene.settings is ignored, like main.go:52, unless -scene-settings asks for the editor's rule (ui/app.go:60-75)
+    scene::RenderSettings s = f.scene_settings ? engine::RenderSettingsForScene(*sc, f.mode) : engine::RenderSettingsForMode(f.mode);
     if (f.width > 0) s.Width = f.width;
     if (f.height > 0) s.Height = f.height;
     if (f.spp >= 0) s.SamplesPerPx = f.spp;

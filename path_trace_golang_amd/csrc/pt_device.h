@@ -129,7 +129,8 @@ struct DevFrame {
     int32_t bvh_stack;                // traversal stack entries per lane (LDS)
     int32_t bvh_lds_nodes;            // top-level nodes of the main tree staged in LDS
     int32_t bvh_min_lanes;            // a traversal loop with fewer lanes still walking leaves them for the next trip
-    int32_t pad_i[1];
+    uint32_t debug_drop;              // verify instantiations only (PTCORE_DEBUG_DROP): candidate bits cleared on purpose, so that
+                                      // the disagreement counter can be shown to move
     int32_t broad_ok;    // 1: at most 32 sphere records and 32 box records -> candidate-bitmask scan usable;
                          // 2: at most 128 of each -> the same in groups of 32 (SCAN_BROAD_WIDE)
     uint32_t sph_all, box_all;    // (1 << n_bsph) - 1, (1 << n_bbox) - 1

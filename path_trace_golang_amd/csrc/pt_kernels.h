@@ -289,7 +289,7 @@ __device__ __forceinline__ bool wins(int mode, bool is_box, int i, double t, int
 }
 
 // Broad phase in FP32 over inflated bounds + exact FP64 narrow phase over the survivors.
-template <bool PROF, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
+template <bool PROF, bool DBG, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
 __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_obj, SphPtr g_bs, BoxPtr g_bb, IdxPtr g_pl,
                                                   const DevObj *s_obj, const int *s_kidx, const RayD &r, const Clip &clip,
                                                   int mode, int &best, double &tmax, const ProfHooks &ph) {
@@ -367,6 +367,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     if (!trust) { cs = F.sph_all; cb = F.box_all; }
     if (outside_all) { cs = 0; cb = 0; }
     if (mode != 0) { cs &= F.sph_diel; cb &= F.box_diel; }
+    if (DBG) { cs &= ~F.debug_drop; cb &= ~F.debug_drop; }
     PH_END(SEC_BROAD)
 
     // ---- narrow phase: spheres, then boxes, each lane on its own candidates (index order)
@@ -415,7 +416,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
 // candidate mask at a time, so no more registers than the single-group version), the dielectric mask of a
 // group is collected from the records on the scalar unit.  Between ~33 and ~200 objects this linear scan at
 // full lanes beats the hierarchy, whose walks diverge.
-template <bool PROF, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
+template <bool PROF, bool DBG, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
 __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr g_obj, SphPtr g_bs, BoxPtr g_bb, IdxPtr g_pl,
                                                        const DevObj *s_obj, const int *s_kidx, const RayD &r, const Clip &clip,
                                                        int mode, int &best, double &tmax, const ProfHooks &ph) {
@@ -475,6 +476,7 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
         if (!trust) cs = cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
         if (outside_all) cs = 0;
         if (mode != 0) cs &= diel;
+        if (DBG) cs &= ~F.debug_drop;
         PH_END(SEC_BROAD)
         while (__ballot(cs != 0) != 0) {
             if (cs != 0) {
@@ -515,6 +517,7 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
             if (!trust) cb = cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
             if (outside_all) cb = 0;
             if (mode != 0) cb &= diel;
+            if (DBG) cb &= ~F.debug_drop;
             PH_END(SEC_BROAD)
             while (__ballot(cb != 0) != 0) {
                 if (cb != 0) {
@@ -1052,9 +1055,9 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     trav.live = false;  // a complete answer: whatever walk was pending is obsolete
                 } else {
                     if (WIDE)
-                        scan_broad_narrow_wide<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
+                        scan_broad_narrow_wide<PROF, VERIFY>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
                     else if (BITMASK)
-                        scan_broad_narrow<PROF>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
+                        scan_broad_narrow<PROF, VERIFY>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
                     else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
                         scanned = scan_bvh<PROF, true>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x,
                                                        ray, clip, mode, trav, best, tmax, ph);
@@ -1338,7 +1341,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         atomicAdd(&B.counters[2], (unsigned long long)w_draw);
         atomicAdd(&B.counters[3], (unsigned long long)w_samples);
     }
-    if (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_BVH) {
+    if (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_BVH || SCAN == SCAN_VERIFY_WIDE) {
         const uint32_t w_mis = wave_sum(c_mismatch);
         if (lane == 0 && w_mis) atomicAdd(&B.counters[4], (unsigned long long)w_mis);
     }

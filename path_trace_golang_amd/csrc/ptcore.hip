@@ -777,6 +777,8 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     const size_t stack_bytes = (size_t)F.bvh_stack * PT_BLOCK * sizeof(int);
     F.bvh_lds_nodes = 0;
     F.bvh_min_lanes = 24;
+    F.debug_drop = 0;  // PTCORE_DEBUG_DROP=<mask>: the verify instantiations of the bitmask scans lose these candidate bits
+    if (const char *e = std::getenv("PTCORE_DEBUG_DROP")) F.debug_drop = (uint32_t)std::strtoul(e, nullptr, 0);
     if (const char *e = std::getenv("PTCORE_BVH_MIN_LANES")) F.bvh_min_lanes = std::max(0, std::min(64, std::atoi(e)));
     if (big && F.bvh_root == 0 && stack_bytes < 40960)
         F.bvh_lds_nodes = (int32_t)std::min<size_t>((40960 - stack_bytes) / sizeof(BvhNode), (size_t)F.bvh_main_nodes);

@@ -88,6 +88,24 @@ def render_settings_for_mode(mode: str) -> scn.RenderSettings:
     return scn.RenderSettings(400, 225, 20, 20)
 
 
+def render_settings_for_scene(sc: scn.Scene, mode: str) -> scn.RenderSettings:
+    """The editor's scene-settings override, internal/ui/app.go:60-75: the mode preset, replaced by the scene's
+    width x height when both are > 0 (and only then by its samples_per_px / max_depth when > 0); a "final"
+    render then takes 4x the samples and 2x the depth.  cmd/render itself ignores scene.settings (main.go:52)."""
+    s = render_settings_for_mode(mode)
+    st = sc.settings
+    if st.width > 0 and st.height > 0:
+        s.width, s.height = st.width, st.height
+        if st.samples_per_px > 0:
+            s.samples_per_px = st.samples_per_px
+        if st.max_depth > 0:
+            s.max_depth = st.max_depth
+    if mode == "final":
+        s.samples_per_px *= 4
+        s.max_depth *= 2
+    return s
+
+
 def save_png(path: str, img: np.ndarray) -> None:
     """SavePNG, util.go:45-55: 8-bit RGBA PNG."""
     from PIL import Image

@@ -104,3 +104,29 @@ def test_many_planes_and_more_than_32_of_a_kind(gpu_ctx, oracle):
         p = rng.uniform([-3, 0.3, -3], [3, 3, 3])
         objs.append({"type": "sphere", "position": V(*p), "size": V(0.3, 0, 0), "material_id": "dgmr"[i % 4]})
     _check(gpu_ctx, oracle, {"camera": CAM, "sky": SKY, "objects": objs, "materials": MATS}, spp=3, depth=6)
+
+
+def test_unknown_object_material_and_sky_types_follow_the_reference(gpu_ctx, oracle):
+    """The reference's default branches through the HIP path: an unknown object type is skipped
+    (objects.go:237-266), an unknown material type is lambert (materials.go:51-53), a sky block with an
+    unknown type falls back to `background` (renderer.go:84-88)."""
+    mats = MATS + [{"id": "v", "type": "velvet", "albedo": {"r": 0.3, "g": 0.8, "b": 0.4}, "rough": 0.2}]
+    objs = [{"type": "plane", "position": V(0, 0, 0), "material_id": "d"},
+            {"type": "torus", "position": V(0, 1, 2), "size": V(1, 1, 1), "material_id": "m"},          # dropped from the world
+            {"type": "sphere", "position": V(-1.2, 1, 0), "size": V(0.9, 0, 0), "material_id": "v"},     # lambert, rough 0.2
+            {"type": "box", "position": V(1.2, 0.75, 0), "size": V(1.5, 1.5, 1.5), "material_id": "v"},
+            {"type": "sphere", "position": V(0, 2.2, -1), "size": V(0.6, 0, 0), "material_id": "nope"}]  # missing id: zero material
+    weird_sky = {"type": "weird", "color": {"r": 9, "g": 9, "b": 9}, "horizon": {"r": 1, "g": 0, "b": 0}, "zenith": {"r": 0, "g": 0, "b": 1}}
+    bg = {"r": 0.25, "g": 0.5, "b": 0.75}
+    o = _check(gpu_ctx, oracle, {"camera": CAM, "sky": weird_sky, "background": bg, "objects": objs, "materials": mats}, spp=4, depth=6)
+    # the torus really is gone: the same scene without it gives the same picture
+    o2 = _check(gpu_ctx, oracle, {"camera": CAM, "sky": weird_sky, "background": bg, "objects": objs[:1] + objs[2:], "materials": mats},
+                spp=4, depth=6)
+    assert np.array_equal(o["rgba"], o2["rgba"])
+    # a primary ray that leaves the scene returns `background`, not any of the sky block's colours
+    top = o["accum"][0, 0] / 4.0
+    assert np.allclose(top, [0.25, 0.5, 0.75], rtol=0, atol=1e-15)
+    # each on its own as well
+    _check(gpu_ctx, oracle, {"camera": CAM, "sky": SKY, "objects": objs[:2], "materials": mats})
+    _check(gpu_ctx, oracle, {"camera": CAM, "sky": SKY, "objects": [objs[0], objs[2]], "materials": mats})
+    _check(gpu_ctx, oracle, {"camera": CAM, "sky": weird_sky, "background": bg, "objects": [], "materials": []})

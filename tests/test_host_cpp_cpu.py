@@ -31,6 +31,7 @@ def host():
     L.pth_scene_encode.argtypes = [C.c_void_p]
     L.pth_scene_save.argtypes = [C.c_void_p, C.c_char_p]
     L.pth_settings_for_mode.argtypes = [C.c_char_p, C.POINTER(C.c_int32)]
+    L.pth_settings_for_scene.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]
     L.pth_save_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.pth_render_into.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
@@ -267,3 +268,46 @@ def test_save_text_is_encoding_json_text_in_both_mirrors(host):
         h = host.pth_scene_decode(raw.encode())
         assert host.pth_scene_encode(h).decode() == scene.dumps(scene.Scene.decode(json.loads(raw)))
         host.pth_scene_free(h)
+
+
+def test_scene_settings_override_follows_the_editor_rule(host, tmp_path):
+    """internal/ui/app.go:60-75 in the C++ and the Python mirror: the scene's width x height replace the preset only when
+    both are > 0, samples / depth only inside that branch and only when > 0; "final" then takes 4x samples, 2x depth."""
+    import json
+
+    from path_trace_golang_amd import engine, scene
+
+    # (settings block in the file) -> expected (preview, final)
+    cases = [
+        ("example_simple", (400, 225, 20, 10), (400, 225, 80, 20)),          # 400x225, 20 spp, depth 10 in the file
+        ("gpu_showcase", (800, 450, 1, 12), (800, 450, 4, 24)),               # 800x450, 1 spp, depth 12
+        ("metal_glass_room", (400, 225, 20, 20), (1920, 1080, 4000, 160)),    # all zero: the preset stays (final: x4, x2)
+    ]
+    out = (C.c_int32 * 4)()
+    for name, prev, fin in cases:
+        h = host.pth_scene_load(scene_path(name).encode())
+        sc = scene.load(scene_path(name))
+        for mode, want in (("preview", prev), ("final", fin)):
+            host.pth_settings_for_scene(h, mode.encode(), out)
+            assert tuple(out) == want, (name, mode)
+            s = engine.render_settings_for_scene(sc, mode)
+            assert (s.width, s.height, s.samples_per_px, s.max_depth) == want, (name, mode)
+        host.pth_scene_free(h)
+    # width without height: nothing of the block applies, not even samples / depth
+    doc = json.load(open(scene_path("example_simple")))
+    doc["settings"] = {"width": 640, "height": 0, "samples_per_px": 7, "max_depth": 3}
+    p = tmp_path / "half.json"
+    p.write_text(json.dumps(doc))
+    h = host.pth_scene_load(str(p).encode())
+    host.pth_settings_for_scene(h, b"preview", out)
+    assert tuple(out) == (400, 225, 20, 20)
+    host.pth_scene_free(h)
+    s = engine.render_settings_for_scene(scene.load(str(p)), "preview")
+    assert (s.width, s.height, s.samples_per_px, s.max_depth) == (400, 225, 20, 20)
+    # both sizes set, samples zero: size and depth from the file, samples from the preset
+    doc["settings"] = {"width": 64, "height": 36, "samples_per_px": 0, "max_depth": 5}
+    p.write_text(json.dumps(doc))
+    h = host.pth_scene_load(str(p).encode())
+    host.pth_settings_for_scene(h, b"final", out)
+    assert tuple(out) == (64, 36, 4000, 10)
+    host.pth_scene_free(h)

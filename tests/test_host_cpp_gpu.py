@@ -28,6 +28,14 @@ def test_cli_headless_matches_oracle(tmp_path, oracle, gpu_ctx):
                        capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert r.returncode == 0, r.stderr
     assert Image.open(out).size == (400, 225)  # the preview preset, scene.settings ignored (main.go:52)
+    # -scene-settings: the editor's override (ui/app.go:60-75): gpu_showcase asks for 800x450, 1 spp, depth 12
+    r = subprocess.run([exe, "-headless", "-gpu", "-scene-settings", "-scene", scene_path("gpu_showcase"), "-out", out, "-seed", "5"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "rendered 800x450, 1 spp, depth 12" in r.stderr
+    o = oracle.render(oracle.Scene.load(scene_path("gpu_showcase")), 800, 450, 1, 12, seed=5, want=("rgba",))
+    im = Image.open(out)
+    assert im.size == (800, 450) and np.array_equal(np.array(im.convert("RGB")), o["rgba"][..., :3])
 
 
 def test_render_into_with_progress(oracle, gpu_ctx):
