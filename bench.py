@@ -188,30 +188,48 @@ def main() -> int:
     if rank == 0:
         steps = max(1, args.steps)
         trace_ms = sum(s.trace_ms for s in stats)
-        n_launch = sum(s.trace_launches for s in stats)
+        glass_ms = sum(s.glass_ms for s in stats)
         resolve_ms = sum(s.resolve_ms for s in stats)
-        avg_launch_s = (trace_ms / max(1, n_launch)) * 1e-3
-        # algorithmic HBM bytes of one trace launch, per sample: the primary ray written by raygen_kernel
-        # (6 doubles + 8 B stream state + 2 B draw count = 58 B) in, 24 B of radiance out
         chunk = stats[0].spp_chunk if stats else 0
-        spp_per_launch = args.spp / max(1, (n_launch / steps))
-        jobs_per_launch = (sum(s.samples for s in stats) / steps) / max(1e-9, args.spp) * spp_per_launch
-        alg_bytes = (58.0 + 24.0) * jobs_per_launch
-        achieved_gbs = alg_bytes / max(avg_launch_s, 1e-12) / 1e9
+        n_samples = float(sum(s.samples for s in stats))
+        split_launches = sum(s.trace_split_launches for s in stats)
+        if split_launches > 0:
+            # dominant kernel: the split form of the trace kernel.  Its algorithmic HBM bytes: 58 B per fresh sample
+            # (primary ray written by raygen_kernel: 6 doubles + 8 B stream state + 2 B draw count), 88 B per path taken
+            # up from the continuation queue (9 doubles + stream state + job + depth), 24 B of radiance per path that
+            # ends in it, 100 B per path it parks in the glass queue (10 doubles + stream state + job, depth, object)
+            kernel_name = "ptk::trace_kernel<false,false,1,true>"
+            n_launch = split_launches
+            k_ms = sum(s.trace_split_ms for s in stats)
+            alg_total = (58.0 * n_samples + 88.0 * sum(s.split_cont_in for s in stats) + 24.0 * sum(s.split_finished for s in stats)
+                         + 100.0 * sum(s.glass_events for s in stats))
+            alg_note = ("register-resident paths between dielectric bounces: per launch 58 B per fresh sample in, 88 B per continuation in, "
+                        "24 B radiance out per path ending, 100 B out per path parked for glass_kernel; the binding resource is VALU "
+                        "issue, see roofline_fp64")
+        else:
+            kernel_name = "ptk::trace_kernel<false,false,1,false>"
+            n_launch = sum(s.trace_launches for s in stats)
+            k_ms = trace_ms
+            alg_total = (58.0 + 24.0) * n_samples
+            alg_note = ("register-resident paths: HBM carries 82 B per SAMPLE (primary ray in, radiance out), nothing per bounce; "
+                        "the binding resource is VALU issue, see roofline_fp64")
+        avg_launch_s = (k_ms / max(1, n_launch)) * 1e-3
+        alg_bytes = alg_total / max(1, n_launch)
+        achieved_gbs = alg_total / max(k_ms * 1e-3, 1e-12) / 1e9
         traffic = None
         traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_cfg = (world == 1 and args.scene == "gpu_showcase" and (W, H, args.spp, args.depth) == (1920, 1080, 1024, 8)
                        and args.spp_chunk == 0)
-        if os.path.exists(tpath) and default_cfg:  # the PMC passes were taken on exactly this launch shape
+        if os.path.exists(tpath) and default_cfg:  # the PMC passes were taken on exactly this workload and launch shape
             try:
                 with open(tpath) as f:
-                    tk = json.load(f).get("trace_kernel", {})
-                # PMC bytes per sample of a full-chunk launch x the samples of this run's average launch
-                traffic = tk["hbm_bytes_per_sample"] * jobs_per_launch if tk.get("hbm_bytes_per_sample") else None
-                if traffic is not None:
-                    traffic_source = ("NOT measured in this run: %.2f B/sample from profiles/pmc_traffic.json [%s] x this run's "
-                                      "samples per launch" % (tk["hbm_bytes_per_sample"], tk.get("source", "?")))
+                    tk = json.load(f).get(kernel_name, {})
+                # PMC bytes per algorithmic byte of the profiled launches x this run's algorithmic bytes per launch
+                if tk.get("hbm_bytes_per_alg_byte"):
+                    traffic = tk["hbm_bytes_per_alg_byte"] * alg_bytes
+                    traffic_source = ("NOT measured in this run: %.3f HBM bytes per algorithmic byte from profiles/pmc_traffic.json [%s] x this "
+                                      "run's algorithmic bytes per launch" % (tk["hbm_bytes_per_alg_byte"], tk.get("source", "?")))
             except Exception:
                 traffic = None
         objs = [o.type for o in sc.objects]
@@ -219,7 +237,8 @@ def main() -> int:
         n_box = sum(1 for t in objs if t == "box")
         n_pl = sum(1 for t in objs if t == "plane")
         fseg = seg_flops(n_sph, n_box, n_pl)
-        rank0_seg_per_s = sum(s.segments for s in stats) / max(trace_ms * 1e-3, 1e-12)
+        # kernel rate of the path work: every trace pass plus glass_kernel
+        rank0_seg_per_s = sum(s.segments for s in stats) / max((trace_ms + glass_ms) * 1e-3, 1e-12)
         fp64_tops = rank0_seg_per_s * fseg / 1e12
         out = {
             "metric": "Msamples/s (rays x bounces/s) at %dx%dx%dspp" % (W, H, args.spp),
@@ -246,17 +265,18 @@ def main() -> int:
             "pixel_rmse_vs_cpu_ref": None,
             "timed_region": "K whole frames: 5 KB scene upload, ray generation, trace, resolve, tile gather (N > 1) and untile; "
                             "the RGBA8 frame stays in HBM on rank 0, its 8.3 MB D2H copy (~0.2 ms) is excluded",
-            "roofline": {"bound": "hbm", "kernel": "ptk::trace_kernel<false,false,1>", "achieved": achieved_gbs,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "alg_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": n_launch / steps,
-                         "note": "register-resident paths: HBM carries 82 B per SAMPLE (primary ray in, radiance "
-                                 "out), nothing per bounce; the binding resource is VALU issue, see roofline_fp64"},
+                         "note": alg_note},
             "roofline_fp64": {"bound": "fp64_valu", "achieved": fp64_tops, "peak": FP64_PEAK_NOFMA_TOPS,
                               "unit": "Tflop/s (unfused)", "frac": fp64_tops / FP64_PEAK_NOFMA_TOPS,
                               "frac_of_fma_peak": fp64_tops / (2.0 * FP64_PEAK_NOFMA_TOPS),
                               "alg_flops_per_segment": fseg,
-                              "trace_share_of_step": trace_ms / max(elapsed * 1e3, 1e-9),
+                              "trace_share_of_step": (trace_ms + glass_ms) / max(elapsed * 1e3, 1e-9),
+                              "trace_ms_per_step": trace_ms / steps, "glass_ms_per_step": glass_ms / steps,
+                              "glass_events_per_segment": sum(s.glass_events for s in stats) / max(1.0, float(sum(s.segments for s in stats))),
                               "raygen_ms_per_step": sum(s.raygen_ms for s in stats) / steps,
                               "resolve_ms_per_step": resolve_ms / steps},
         }

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 /* status codes; pt_last_error() holds the text (thread-local) */
 enum {
@@ -156,6 +156,15 @@ typedef struct pt_stats {
     int32_t num_devices;
     double per_device_ms[8];
     double raygen_ms;    /* device time inside the ray-generation kernel(s) */
+    /* split passes (ABI 2): dielectric hits leave the trace kernel through a path-state queue and are shaded by glass_kernel */
+    double glass_ms;       /* device time inside glass_kernel */
+    double trace_split_ms; /* the part of trace_ms spent in the split form of the trace kernel (the dominant launches) */
+    int32_t glass_launches;
+    int32_t trace_split_launches;
+    uint64_t glass_events;    /* paths parked in the glass queue by the split trace passes (= dielectric closest hits there) */
+    uint64_t continuations;   /* paths glass_kernel handed back through the continuation queue */
+    uint64_t split_cont_in;   /* continuation entries taken up by split trace passes (the rest finish in the all-in-one pass) */
+    uint64_t split_finished;  /* paths that ended inside a split trace pass */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

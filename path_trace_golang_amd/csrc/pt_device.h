@@ -44,8 +44,12 @@ struct alignas(8) DevMat {
     int32_t typ;
     int32_t absorbs;   // absorption.x > 0 || .y > 0 || .z > 0 (renderer.go:360)
     double rough_sq;   // rough*rough (materials.go:121)
+    // dielectric only, the same IEEE operations the reference performs on every hit, done once on the host:
+    double inv_ior;    // 1.0 / ior                                (materials.go:183, front face)
+    double r0_front;   // ((1 - 1/ior) / (1 + 1/ior))^2            (materials.go:227-228 with ratio = 1/ior)
+    double r0_back;    // ((1 - ior) / (1 + ior))^2                (ratio = ior)
 };
-static_assert(sizeof(DevMat) == 104, "DevMat layout");
+static_assert(sizeof(DevMat) == 128, "DevMat layout");
 
 // Broad-phase records (FP32, read with scalar loads): conservative bounds of the finite
 // objects, inflated by `m = 2^-12 * scene bound` and rounded outward, so that an FP32 test
@@ -59,8 +63,8 @@ struct alignas(16) BroadSphere {
 };
 static_assert(sizeof(BroadSphere) == 32, "BroadSphere layout");
 struct alignas(16) BroadBox {
-    float lo[3];       // min - m, rounded down
-    float hi[3];       // max + m, rounded up
+    float c[3];        // centre of [min - m, max + m]
+    float h[3];        // half extent, rounded up so that [c - h, c + h] holds [min - m, max + m]
     int32_t index;
     int32_t diel;      // 1: the object is dielectric
 };
@@ -118,7 +122,9 @@ struct DevFrame {
     int32_t nlocal;      // tiles owned by this shard
     uint32_t s0;         // first sample index of the chunk
     uint32_t S;          // samples per pixel in the chunk
-    uint32_t njobs;      // nlocal*16*S*64
+    uint32_t njobs;      // nlocal*16*S*64 (also the plane stride of the primary-ray buffers)
+    uint32_t fresh;      // fresh jobs this trace pass takes (njobs for a first pass, 0 for a pass over continuations only)
+    int32_t n_dsph, n_dbox;  // dielectric-only broad-phase records (bsph_diel / bbox_diel)
     uint32_t claim;      // jobs a wave claims per queue pop (multiple of 64)
     int32_t n_bsph, n_bbox, n_plane;  // broad-phase record counts; planes are always tested exactly
     int32_t n_bvh_nodes, n_bvh_objs;  // BVH path (scenes beyond 128 spheres / 128 boxes)
@@ -145,6 +151,24 @@ struct DevFrame {
     double height_m1;    // H-1      renderer.go:98
 };
 
+// Path states parked in HBM between passes (SoA, `cap` entries per plane; entries are appended with one
+// wave-aggregated atomic per push, so the lanes of a push write consecutive slots).
+//   glass queue        paths whose closest hit is a dielectric: the incoming ray, the hit (object index, t), throughput,
+//                      stream state, depth.  glass_kernel scatters them (materials.go:162-200), runs the exit search
+//                      (renderer.go:316-371) and Russian roulette, all lanes on the same branch.
+//   continuation queue paths that go on after their dielectric bounce; the next trace pass takes them like fresh jobs.
+struct PathQueue {
+    double *d;                  // [10][cap]: ox oy oz dx dy dz Tx Ty Tz tmax
+    unsigned long long *rs;     // [cap] stream state
+    uint32_t *job;              // [cap]
+    int32_t *depth;             // [cap] remaining depth (renderer.go:286 counts down)
+    int32_t *best;              // [cap] glass queue: object hit
+    uint32_t *jseg, *jdraw;     // [cap] per-job counters so far (PT_FLAG_PIXEL_STATS) or null
+    uint32_t *count;            // entries appended so far
+    uint32_t cap;
+    uint32_t pad;
+};
+
 struct TraceBuffers {
     const DevObj *objs;
     const DevMat *mats;
@@ -162,6 +186,18 @@ struct TraceBuffers {
     unsigned int *queue;  // job queue head
     unsigned long long *counters;  // [4]: segments, exit_scans, draws, samples
     unsigned long long *prof;      // diagnostic build only: [SEC_COUNT][3] executions, lanes, cycles
+    PathQueue glass;               // split passes: dielectric hits leave the trace kernel here
+    PathQueue cont;                // continuation entries: read by trace_kernel (cont_in of them), written by glass_kernel
+    const uint32_t *cont_in;       // number of continuation entries this trace pass starts from (device word; 0 for a first pass)
+    const BroadSphere *bsph_diel;  // broad-phase records of the dielectric objects only (exit searches of glass_kernel)
+    const BroadBox *bbox_diel;
+};
+
+// The argument block of trace_kernel (one by-value kernel argument, i.e. the kernarg segment).
+struct TraceArgs {
+    DevFrame F;
+    DevSky sky;
+    TraceBuffers B;
 };
 
 }  // namespace ptd

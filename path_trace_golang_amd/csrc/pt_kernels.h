@@ -44,6 +44,9 @@ using namespace ptd;
 
 #define PT_WAVE 64
 #define PT_BLOCK 256
+#define PT_QUEUE_BLOCK 256u     // glass-queue slots a wave of trace_kernel reserves per atomic
+#define PT_CONT_BLOCK 1024u     // continuation slots a wave of glass_kernel reserves per atomic
+#define PT_HOLE 0xffffffffu     // job id of a reserved but unused queue slot
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -288,11 +291,39 @@ __device__ __forceinline__ bool wins(int mode, bool is_box, int i, double t, int
     return best_is_box || i > best;
 }
 
+// The record lists one bitmask scan runs over: every finite object (closest-hit scans, and exit searches of the
+// all-in-one kernel, which mask the dielectric ones) or the dielectric objects only (exit searches of glass_kernel).
+template <typename SphPtr, typename BoxPtr>
+struct BroadLists {
+    SphPtr bs;             // sphere records (scalar loads)
+    BoxPtr bb;             // box records
+    int n_bsph, n_bbox;    // <= 32 each
+    uint32_t sph_all, box_all;    // (1 << n) - 1
+    uint32_t sph_diel, box_diel;  // records whose object is dielectric
+    const int *kidx_s;     // LDS: record -> object index
+    const int *kidx_b;
+};
+
+// Slab parameters of one inflated box from its centre c and half extent h (both rounded so that [c-h, c+h] holds the
+// inflated box): t = (c -+ h - o) / d = c*iv - o*iv -+ h*|iv|, i.e. three fma per axis and no min/max to order the
+// two slab planes (v_min/v_max_f32 cost a gfx950 SIMD 4 cycles per wave, an fma pair packs into one 4-cycle v_pk_fma:
+// profiles/r02_valu_floor.json).  A zero direction component gives iv = inf and NaN or +-inf parameters, which
+// v_max3/v_min3 skip or which bound nothing: that slab then constrains nothing (conservative).
+#define PT_BOX_SLABS(bx, tn, tf)                                                                                       \
+    const float tcx_ = __builtin_fmaf(bx.c[0], ivxf, noxf), tcy_ = __builtin_fmaf(bx.c[1], ivyf, noyf),                \
+                tcz_ = __builtin_fmaf(bx.c[2], ivzf, nozf);                                                            \
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(-bx.h[0], aivxf, tcx_), __builtin_fmaf(-bx.h[1], aivyf, tcy_)), \
+                                     __builtin_fmaxf(__builtin_fmaf(-bx.h[2], aivzf, tcz_), tminf));                   \
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bx.h[0], aivxf, tcx_), __builtin_fmaf(bx.h[1], aivyf, tcy_)),   \
+                                     __builtin_fmaf(bx.h[2], aivzf, tcz_));
+
 // Broad phase in FP32 over inflated bounds + exact FP64 narrow phase over the survivors.
-template <bool PROF, bool DBG, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
-__device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_obj, SphPtr g_bs, BoxPtr g_bb, IdxPtr g_pl,
-                                                  const DevObj *s_obj, const int *s_kidx, const RayD &r, const Clip &clip,
-                                                  int mode, int &best, double &tmax, const ProfHooks &ph) {
+// MODE: 0 closest hit, 1 exit search, -1 decided per lane by `mode_rt`.
+template <bool PROF, bool DBG, int MODE, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
+__device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_obj, const BroadLists<SphPtr, BoxPtr> &BL, IdxPtr g_pl,
+                                                  const DevObj *s_obj, const RayD &r, const Clip &clip,
+                                                  int mode_rt, int &best, double &tmax, const ProfHooks &ph) {
+    const int mode = MODE < 0 ? mode_rt : MODE;
     const double tmin = mode ? 0.0001 : 0.001;
     tmax = ptm::max_float64();
     best = -1;
@@ -304,9 +335,11 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     for (int k = 0; k < F.n_plane; k++) {
         const int i = g_pl[k];
         const auto &o = g_obj[i];
-        if (mode != 0 && !(o.kind & 0x100)) continue;
+        if (MODE == 1 && !(o.kind & 0x100)) continue;  // wave-uniform
         double t = 0;
-        if (plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t)) {
+        bool acc = plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t);
+        if (MODE < 0 && mode != 0 && !(o.kind & 0x100)) acc = false;
+        if (acc) {
             if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
                           : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_PLANE, r, t))) {
                 best = i;
@@ -334,8 +367,8 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     // candidate masks: bit k of `cs` = k-th sphere record, bit k of `cb` = k-th box record (<= 32 of each;
     // the bit is wave-uniform, so setting it costs one select and one or)
     uint32_t cs = 0, cb = 0;
-    for (int k = 0; k < F.n_bsph; k++) {
-        const auto &s = g_bs[k];
+    for (int k = 0; k < BL.n_bsph; k++) {
+        const auto &s = BL.bs[k];
         const float ocx = fox - s.cx, ocy = foy - s.cy, ocz = foz - s.cz;
         const float b = __builtin_fmaf(ocx, fdx, __builtin_fmaf(ocy, fdy, ocz * fdz));
         const float tca = -b * inv_a;  // parameter of closest approach
@@ -348,25 +381,24 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         cs = miss ? cs : (cs | (1u << k));
     }
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
-    // slab parameters as lo * (1/d) - o/d: one fma each; the extra rounding (~2^-24 |o| in distance) is far inside
-    // the margin, and inf - inf = NaN for a zero direction component leaves that slab unconstrained
+    const float aivxf = __builtin_fabsf(ivxf), aivyf = __builtin_fabsf(ivyf), aivzf = __builtin_fabsf(ivzf);
+    // -o/d: the extra rounding (~2^-24 |o| in distance) is far inside the margin, and inf - inf = NaN for a zero
+    // direction component leaves that slab unconstrained
     const float noxf = -fox * ivxf, noyf = -foy * ivyf, nozf = -foz * ivzf;
-    for (int k = 0; k < F.n_bbox; k++) {
-        const auto &bx = g_bb[k];
-        const float tax = __builtin_fmaf(bx.lo[0], ivxf, noxf), tbx = __builtin_fmaf(bx.hi[0], ivxf, noxf);
-        const float tay = __builtin_fmaf(bx.lo[1], ivyf, noyf), tby = __builtin_fmaf(bx.hi[1], ivyf, noyf);
-        const float taz = __builtin_fmaf(bx.lo[2], ivzf, nozf), tbz = __builtin_fmaf(bx.hi[2], ivzf, nozf);
-        // v_min/v_max return the other operand for a NaN: a NaN slab (0 * inf) constrains nothing
-        const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)),
-                                         __builtin_fmaxf(__builtin_fminf(taz, tbz), tminf));
-        const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
-                                         __builtin_fmaxf(taz, tbz));
+    for (int k = 0; k < BL.n_bbox; k++) {
+        const auto &bx = BL.bb[k];
+        PT_BOX_SLABS(bx, t0, t1)
         const bool miss = t1 < t0;
         cb = miss ? cb : (cb | (1u << k));
     }
-    if (!trust) { cs = F.sph_all; cb = F.box_all; }
+    if (!trust) { cs = BL.sph_all; cb = BL.box_all; }
     if (outside_all) { cs = 0; cb = 0; }
-    if (mode != 0) { cs &= F.sph_diel; cb &= F.box_diel; }
+    if (MODE < 0) {
+        if (mode != 0) { cs &= BL.sph_diel; cb &= BL.box_diel; }
+    } else if (MODE == 1) {
+        cs &= BL.sph_diel;
+        cb &= BL.box_diel;
+    }
     if (DBG) { cs &= ~F.debug_drop; cb &= ~F.debug_drop; }
     PH_END(SEC_BROAD)
 
@@ -375,13 +407,13 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     while (__ballot(ms != 0) != 0) {
         if (ms != 0) {
             PH_BEGIN(SEC_NSPH)
-            const int i = s_kidx[__builtin_ctz(ms)];  // record -> object index; records are in file order
+            const int i = BL.kidx_s[__builtin_ctz(ms)];  // record -> object index; records are in file order
             ms &= ms - 1;
             const DevObj &o = s_obj[i];
             double t = 0;
             bool acc = sphere_exact(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, tmin, tmax, t) &&
                        wins(mode, false, i, t, best, best_is_box, tmax);
-            if (acc && mode != 0) acc = exit_candidate_ok(o, KIND_SPHERE, r, t);
+            if (MODE != 0 && acc && mode != 0) acc = exit_candidate_ok(o, KIND_SPHERE, r, t);
             // selects, not branches: the update is four v_cndmask
             best = acc ? i : best;
             tmax = acc ? t : tmax;
@@ -395,14 +427,14 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         while (__ballot(mb != 0) != 0) {
             if (mb != 0) {
                 PH_BEGIN(SEC_NBOX)
-                const int i = s_kidx[F.n_bsph + __builtin_ctz(mb)];
+                const int i = BL.kidx_b[__builtin_ctz(mb)];
                 mb &= mb - 1;
                 const DevObj &o = s_obj[i];
                 double t = 0;
                 // the range is left open at the top here: `wins` compares t with tmax (strictly for a box)
                 bool acc = box_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t) &&
                            wins(mode, true, i, t, best, best_is_box, tmax);
-                if (acc && mode != 0) acc = exit_candidate_ok(o, KIND_BOX, r, t);
+                if (MODE != 0 && acc && mode != 0) acc = exit_candidate_ok(o, KIND_BOX, r, t);
                 best = acc ? i : best;
                 tmax = acc ? t : tmax;
                 best_is_box = acc ? true : best_is_box;
@@ -454,6 +486,7 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
     tminf -= __builtin_fabsf(tminf) * 1e-2f + 1e-6f;
     const float inv_a = __builtin_amdgcn_rcpf(fa);
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
+    const float aivxf = __builtin_fabsf(ivxf), aivyf = __builtin_fabsf(ivyf), aivzf = __builtin_fabsf(ivzf);
     const float noxf = -fox * ivxf, noyf = -foy * ivyf, nozf = -foz * ivzf;
 
     for (int base = 0; base < F.n_bsph; base += 32) {
@@ -503,13 +536,7 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
             uint32_t cb = 0, diel = 0;
             for (int k = 0; k < cnt; k++) {
                 const auto &bx = g_bb[base + k];
-                const float tax = __builtin_fmaf(bx.lo[0], ivxf, noxf), tbx = __builtin_fmaf(bx.hi[0], ivxf, noxf);
-                const float tay = __builtin_fmaf(bx.lo[1], ivyf, noyf), tby = __builtin_fmaf(bx.hi[1], ivyf, noyf);
-                const float taz = __builtin_fmaf(bx.lo[2], ivzf, nozf), tbz = __builtin_fmaf(bx.hi[2], ivzf, nozf);
-                const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)),
-                                                 __builtin_fmaxf(__builtin_fminf(taz, tbz), tminf));
-                const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)),
-                                                 __builtin_fmaxf(taz, tbz));
+                PT_BOX_SLABS(bx, t0, t1)
                 const bool miss = t1 < t0;
                 cb = miss ? cb : (cb | (1u << k));
                 diel |= bx.diel ? (1u << k) : 0u;
@@ -867,9 +894,128 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_kernel(const DevFrame F, cons
     ray_ndraw[myjob] = (uint16_t)(nd < 0xfffeu ? nd : 0xfffeu);
 }
 
-template <bool STATS, bool PROF, int SCAN>
-__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const DevSky sky, const TraceBuffers B) {
+// ------------------------------------------------------------------------------------------------------------
+// Shading pieces shared by trace_kernel (all-in-one form) and glass_kernel.  Every expression is the reference's,
+// in the reference's association order.
+
+// One draw of the sample stream (random.go:27-34) with the bookkeeping both kernels keep.
+template <bool STATS>
+__device__ __forceinline__ double draw_next(uint64_t &rs, uint32_t &c_draw, uint32_t &j_draw) {
+    c_draw++;
+    if (STATS) j_draw++;
+    return ptm::stream_next(rs);
+}
+
+// material.scatter, dielectric branch (materials.go:162-200) on the unit incoming direction u, the face normal n and
+// the mirror direction rf = reflectVec(u, n).  1/ior and r0 come precomputed per material (DevMat): the same IEEE
+// operations on the same operands the reference repeats on every hit.
+template <bool STATS>
+__device__ __forceinline__ void dielectric_scatter(const DevMat &m, bool ff, double ux, double uy, double uz, double nx, double ny,
+                                                   double nz, double rfx, double rfy, double rfz, uint64_t &rs, uint32_t &c_draw,
+                                                   uint32_t &j_draw, double &ndx, double &ndy, double &ndz) {
+    ndx = rfx; ndy = rfy; ndz = rfz;
+    const double ratio = ff ? m.inv_ior : m.ior;
+    const double cosTheta = ptm::go_min(-(ux * nx + uy * ny + uz * nz), 1.0);
+    const double sinTheta = ptm::f_sqrt(1.0 - cosTheta * cosTheta);
+    const bool cannot = ratio * sinTheta > 1.0;
+    const double r0 = ff ? m.r0_front : m.r0_back;
+    const double reflectProb = r0 + (1 - r0) * ptm::go_pow5(1 - cosTheta);
+    bool reflects = cannot;
+    if (!cannot) {  // Go's || short-circuit: the draw happens only here
+        const double xi = draw_next<STATS>(rs, c_draw, j_draw);
+        reflects = reflectProb > xi;
+    }
+    if (!reflects) {  // refractVec, math.go:48-64
+        const double ct = ptm::go_min(-ux * nx - uy * ny - uz * nz, 1.0);
+        double qx = ux + nx * ct, qy = uy + ny * ct, qz = uz + nz * ct;
+        qx *= ratio; qy *= ratio; qz *= ratio;
+        const double perpLenSq = qx * qx + qy * qy + qz * qz;
+        const double par = -ptm::f_sqrt(ptm::f_abs(1.0 - perpLenSq));
+        ndx = qx + nx * par; ndy = qy + ny * par; ndz = qz + nz * par;
+    }
+}
+
+// After an exit search (renderer.go:352-370): Beer-Lambert attenuation over the distance travelled inside and the
+// origin moved to the exit point; the entry hit point is the ray origin.
+__device__ __forceinline__ void exit_post(const DevMat &m, int best, double tmax, double &ox, double &oy, double &oz, double dx,
+                                          double dy, double dz, double &attx, double &atty, double &attz) {
+    if (best >= 0) {
+        const double px = ox + dx * tmax, py = oy + dy * tmax, pz = oz + dz * tmax;
+        const double ex = px - ox, ey = py - oy, ez = pz - oz;
+        const double distance = ptm::f_sqrt(ex * ex + ey * ey + ez * ez);
+        if (m.absorbs) {
+            attx = ptm::go_exp(-m.absorption[0] * distance);
+            atty = ptm::go_exp(-m.absorption[1] * distance);
+            attz = ptm::go_exp(-m.absorption[2] * distance);
+        }
+        ox = px; oy = py; oz = pz;
+    }
+}
+
+// Russian roulette on the last three levels and the step to the next level (renderer.go:375-403 with
+// renderer.go:287-289 of the callee).  Returns true when the path ends here (it contributes `emitted` = 0).
+template <bool STATS>
+__device__ __forceinline__ bool roulette_advance(int &depth, double attx, double atty, double attz, double &Tx, double &Ty, double &Tz,
+                                                 uint64_t &rs, uint32_t &c_draw, uint32_t &j_draw) {
+    bool finished = false;
+    if (depth <= 3) {  // renderer.go:375-393
+        const double maxAtt = ptm::go_max(attx, ptm::go_max(atty, attz));
+        if (maxAtt < 1e-6) {
+            finished = true;
+        } else {
+            const double rrProb = ptm::go_min(maxAtt, 0.95);
+            const double xi = draw_next<STATS>(rs, c_draw, j_draw);
+            if (xi > rrProb) {
+                finished = true;
+            } else {
+                attx /= rrProb; atty /= rrProb; attz /= rrProb;
+            }
+        }
+    }
+    if (!finished) {
+        Tx *= attx; Ty *= atty; Tz *= attz;
+        depth--;
+        if (depth <= 0) finished = true;  // renderer.go:287-289 contributes zero
+    }
+    return finished;
+}
+
+// Hides where a (wave-uniform) pointer came from, so that what is read through it is re-read at the point of use
+// instead of being kept in scalar registers from the kernel's prologue on.
+template <typename P>
+__device__ __forceinline__ P pt_launder(P p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// Appends the lanes with `push` set to a path queue: one atomic per wave, consecutive slots in lane order.
+// Returns this lane's slot.  The queues hold one entry per job of the chunk at most, so they cannot overflow.
+__device__ __forceinline__ uint32_t queue_reserve(uint32_t *count, bool push, uint32_t lane) {
+    const uint64_t pm = __ballot(push);
+    const uint32_t leader = (uint32_t)__ffsll((long long)pm) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(pm));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+    return base + lane_rank(pm);
+}
+
+// SPLIT: dielectric hits are not shaded here.  The lane parks the path in the glass queue (HBM) and takes the next
+// job; glass_kernel handles them together, and the paths that go on come back through the continuation queue.
+// The trace loop then never runs the dielectric branch, the exit search or its epilogue at 14 % of its lanes,
+// and no lane spends a whole trip through the scan on an exit search.
+template <bool STATS, bool PROF, int SCAN, bool SPLIT>
+__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const TraceArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const DevFrame &F = A.F;
+    const TraceBuffers &B = A.B;  // set-up and epilogue only; the loop reads the argument block through KA
+    // The loop needs some 40 scalars of the argument block once per trip (sky colours, queue and buffer pointers) next
+    // to the ones its scan loops use all the time.  Kept in SGPRs for the whole loop they do not fit, and the compiler
+    // parks them in VGPR lanes: every v_readlane / v_writelane is a 4-cycle VALU instruction in a VALU-bound kernel.
+    // KA re-derives the pointer to the argument block (kernarg segment, constant address space) through an opaque
+    // asm, so those fields are re-read by scalar loads where they are used (SMEM issue, no VALU slot).
+    typedef const TraceArgs __attribute__((address_space(4))) *ConstArgsPtr;
+    const ConstArgsPtr ka = (ConstArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+#define KA (pt_launder(ka))
     constexpr bool BIG = (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH);
     // small scenes: the world is staged in LDS (the winner look-up after the scan is per lane);
     // BVH scenes: LDS holds the traversal stacks and the world is read from HBM/L2
@@ -914,11 +1060,22 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
     const ConstSphPtr g_bs = (ConstSphPtr)(B.bsph);
     const ConstBoxPtr g_bb = (ConstBoxPtr)(B.bbox);
     const ConstIdxPtr g_pl = (ConstIdxPtr)(B.plane_idx);
+    const BroadLists<ConstSphPtr, ConstBoxPtr> BL{g_bs, g_bb, F.n_bsph, F.n_bbox, F.sph_all, F.box_all, F.sph_diel, F.box_diel,
+                                                  lds_kidx, lds_kidx + F.n_bsph};
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
+    const BvhNode *const bvh_nodes_ = B.bvh_nodes;
+    const BvhObj *const bvh_objs_ = B.bvh_objs;
+
+    // work items of this pass: continuation entries [0, n_cont), then fresh jobs [n_cont, n_cont + F.fresh)
+    // (only the scans that have a split form ever see continuation entries)
+    constexpr bool CONT = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY);
+    typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
+    const uint32_t n_cont = CONT ? *(ConstU32Ptr)(B.cont_in) : 0u;
+    const uint32_t n_items = n_cont + F.fresh;
 
     // per-lane path state
     bool active = false;
-    int mode = 0;  // 0: closest-hit scan, 1: dielectric exit search
+    int mode = 0;  // 0: closest-hit scan, 1: dielectric exit search (all-in-one form only)
     int depth = 0;
     int exit_mat = 0;
     uint32_t job = 0;
@@ -928,11 +1085,17 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
     uint32_t c_seg = 0, c_exit = 0, c_draw = 0, c_samples = 0;
     uint32_t j_seg = 0, j_draw = 0;
     uint32_t c_mismatch = 0;  // SCAN_VERIFY only
+    uint32_t c_glass = 0, c_fin = 0, c_contin = 0;  // SPLIT only: paths parked in the glass queue / ended here / taken from the continuation queue
     TravState trav;           // BVH strategies only: an unfinished traversal of this lane's ray
 
-    // wave-uniform job cursor
+    // wave-uniform item cursor
     uint32_t cur = 0, end = 0;
     bool exhausted = false;
+    // wave-uniform window of glass-queue slots this wave has reserved (SPLIT).  One atomic on the queue's counter per
+    // PT_QUEUE_BLOCK slots: a push per wave and trip on ONE address would be ~20 M same-address atomics per launch,
+    // which that address cannot serve (measured: the pass ran 2.5x slower).  Slots a wave has reserved but not filled
+    // when it retires are marked as holes (job = PT_HOLE) and skipped by glass_kernel.
+    uint32_t g_cur = 0, g_end = 0;
 
     // diagnostic counters (registers; only materialised when PROF)
     uint32_t p_exec[SEC_COUNT], p_lanes[SEC_COUNT];
@@ -953,10 +1116,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
 #define SEC_END(id) \
     if (PROF && lead_##id) p_cyc[id] += __builtin_amdgcn_s_memtime() - t_##id;
 
-#define PT_DRAW(var)                 \
-    double var = ptm::stream_next(rs); \
-    c_draw++;                        \
-    if (STATS) j_draw++;
+#define PT_DRAW(var) double var = draw_next<STATS>(rs, c_draw, j_draw);
 
     for (;;) {
         SEC_BEGIN(SEC_ITER)
@@ -965,33 +1125,55 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         if (need != 0) {
             if (cur >= end && !exhausted) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(B.queue, F.claim);
+                if (lane == 0) base = atomicAdd(KA->B.queue, F.claim);
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= F.njobs) {
+                if (base >= n_items) {
                     exhausted = true;
                 } else {
                     cur = base;
-                    end = (F.njobs - base < F.claim) ? F.njobs : base + F.claim;
+                    end = (n_items - base < F.claim) ? n_items : base + F.claim;
                 }
             }
             const uint32_t avail = end - cur;
             const uint32_t rank = lane_rank(need);
             const bool take = !active && rank < avail;
             const uint32_t nneed = (uint32_t)__popcll(need);
-            const uint32_t myjob = cur + rank;
+            const uint32_t item = cur + rank;
             cur += nneed < avail ? nneed : avail;
 
-            if (take) {
+            if (CONT && take && item < n_cont) {
+                // a path that left glass_kernel: its whole state comes from the continuation queue
+                const auto cq = &KA->B.cont;
+                const size_t qc = cq->cap;
+                job = cq->job[item];
+                active = job != PT_HOLE;  // a slot some wave of glass_kernel reserved and did not fill
+                if (SPLIT && active) c_contin++;
+                mode = 0;
+                depth = cq->depth[item];
+                ox = cq->d[item];
+                oy = cq->d[qc + item];
+                oz = cq->d[2 * qc + item];
+                dx = cq->d[3 * qc + item];
+                dy = cq->d[4 * qc + item];
+                dz = cq->d[5 * qc + item];
+                Tx = cq->d[6 * qc + item];
+                Ty = cq->d[7 * qc + item];
+                Tz = cq->d[8 * qc + item];
+                rs = cq->rs[item];
+                if (STATS) { j_seg = cq->jseg[item]; j_draw = cq->jdraw[item]; }
+            } else if (take) {
                 // the primary ray of this job was generated by raygen_kernel (coherent pre-pass)
-                const uint32_t nd = B.ray_ndraw[myjob];
+                const uint32_t myjob = item - n_cont;
+                const auto kb = &KA->B;
+                const uint32_t nd = kb->ray_ndraw[myjob];
                 if (nd != 0xffffu && F.max_depth <= 0) {
                     // rayColorOpt returns black before any scan (renderer.go:287-289); the camera draws happened
                     c_samples++;
                     c_draw += nd;
-                    reinterpret_cast<double4 *>(B.L)[myjob] = make_double4(0.0, 0.0, 0.0, 0.0);
+                    reinterpret_cast<double4 *>(kb->L)[myjob] = make_double4(0.0, 0.0, 0.0, 0.0);
                     if (STATS) {
-                        B.job_seg[myjob] = 0;
-                        B.job_draw[myjob] = nd;
+                        kb->job_seg[myjob] = 0;
+                        kb->job_draw[myjob] = nd;
                     }
                 } else if (nd != 0xffffu) {  // 0xffff: the job's pixel lies outside the frame (edge tile)
                     SEC_BEGIN(SEC_RAYGEN)
@@ -1004,13 +1186,13 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     c_draw += nd;
                     if (STATS) { j_seg = 0; j_draw = nd; }
                     const size_t nj = F.njobs;
-                    ox = B.ray[myjob];
-                    oy = B.ray[nj + myjob];
-                    oz = B.ray[2 * nj + myjob];
-                    dx = B.ray[3 * nj + myjob];
-                    dy = B.ray[4 * nj + myjob];
-                    dz = B.ray[5 * nj + myjob];
-                    rs = B.ray_rng[myjob];
+                    ox = kb->ray[myjob];
+                    oy = kb->ray[nj + myjob];
+                    oz = kb->ray[2 * nj + myjob];
+                    dx = kb->ray[3 * nj + myjob];
+                    dy = kb->ray[4 * nj + myjob];
+                    dz = kb->ray[5 * nj + myjob];
+                    rs = kb->ray_rng[myjob];
                     SEC_END(SEC_RAYGEN)
                 }
             }
@@ -1024,6 +1206,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         }
 
         bool finished = false;
+        bool to_glass = false;  // SPLIT: the hit is a dielectric, the path leaves for the glass queue
         double termx = 0, termy = 0, termz = 0;
 
         int best = -1;
@@ -1033,7 +1216,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             // -------------------------------------------------------- scan
             SEC_BEGIN(SEC_SCAN)
             const RayD ray{ox, oy, oz, dx, dy, dz};
-            const ProfHooks ph{p_exec, p_lanes, p_cyc, lane, B.counters + 8};
+            const ProfHooks ph{p_exec, p_lanes, p_cyc, lane, (PROF && BIG) ? B.counters + 8 : nullptr};
             if (SCAN == SCAN_UNIFORM) {
                 scan_uniform(F, g_obj, ray, mode, best, tmax);
             } else {
@@ -1057,12 +1240,12 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                     if (WIDE)
                         scan_broad_narrow_wide<PROF, VERIFY>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
                     else if (BITMASK)
-                        scan_broad_narrow<PROF, VERIFY>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
+                        scan_broad_narrow<PROF, VERIFY, SPLIT ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
                     else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
-                        scanned = scan_bvh<PROF, true>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x,
+                        scanned = scan_bvh<PROF, true>(F, g_obj, g_pl, bvh_nodes_, lds_nodes, bvh_objs_, lds_stack + threadIdx.x,
                                                        ray, clip, mode, trav, best, tmax, ph);
                     else
-                        scanned = scan_bvh<PROF, false>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x,
+                        scanned = scan_bvh<PROF, false>(F, g_obj, g_pl, bvh_nodes_, lds_nodes, bvh_objs_, lds_stack + threadIdx.x,
                                                         ray, clip, mode, trav, best, tmax, ph);
                     if (VERIFY && scanned) {
                         int best2;
@@ -1070,7 +1253,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                         scan_uniform(F, g_obj, ray, mode, best2, tmax2);
                         if (best != best2 || (best >= 0 && !(tmax == tmax2))) {
                             c_mismatch++;
-                            unsigned long long *dbg = B.counters + 8;  // one disagreeing segment (racy, any one will do)
+                            unsigned long long *dbg = KA->B.counters + 8;  // one disagreeing segment (racy, any one will do)
                             dbg[0] = ((unsigned long long)(uint32_t)best << 32) | (uint32_t)best2;
                             dbg[1] = ptm::to_bits(tmax);
                             dbg[2] = ptm::to_bits(tmax2);
@@ -1089,29 +1272,32 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             // -------------------------------------------------------- shade
             bool do_rr = false;
             double attx = 1, atty = 1, attz = 1;
-            if (mode == 0) {
+            if (SPLIT || mode == 0) {
                 c_seg++;
                 if (STATS) j_seg++;
                 if (best < 0) {
                     // sky closure, renderer.go:56-92
                     SEC_BEGIN(SEC_SKY)
                     finished = true;
-                    if (sky.kind == 1) {
+                    const auto sky = &KA->sky;
+                    if (sky->kind == 1) {
                         const double dirLen = ptm::f_sqrt(dx * dx + dy * dy + dz * dz);
                         if (dirLen == 0) {
-                            termx = sky.c0[0]; termy = sky.c0[1]; termz = sky.c0[2];
+                            termx = sky->c0[0]; termy = sky->c0[1]; termz = sky->c0[2];
                         } else {
                             double tt = (dy / dirLen + 1.0) * 0.5;
                             if (tt < 0) tt = 0;
                             if (tt > 1) tt = 1;
-                            termx = sky.c0[0] * (1 - tt) + sky.c1[0] * tt;
-                            termy = sky.c0[1] * (1 - tt) + sky.c1[1] * tt;
-                            termz = sky.c0[2] * (1 - tt) + sky.c1[2] * tt;
+                            termx = sky->c0[0] * (1 - tt) + sky->c1[0] * tt;
+                            termy = sky->c0[1] * (1 - tt) + sky->c1[1] * tt;
+                            termz = sky->c0[2] * (1 - tt) + sky->c1[2] * tt;
                         }
                     } else {
-                        termx = sky.c0[0]; termy = sky.c0[1]; termz = sky.c0[2];
+                        termx = sky->c0[0]; termy = sky->c0[1]; termz = sky->c0[2];
                     }
                     SEC_END(SEC_SKY)
+                } else if (SPLIT && (s_obj[best].kind & 0x100)) {
+                    to_glass = true;  // dielectric: shaded by glass_kernel
                 } else {
                     SEC_BEGIN(SEC_HITREC)
                     const DevObj &o = s_obj[best];
@@ -1221,28 +1407,9 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                                 }
                                 SEC_END(SEC_COSINE)
                             }
-                            if (typ == MAT_DIELECTRIC) {  // materials.go:162-200
+                            if (!SPLIT && typ == MAT_DIELECTRIC) {  // materials.go:162-200
                                 SEC_BEGIN(SEC_DIEL)
-                                const double ratio = ff ? 1.0 / m.ior : m.ior;
-                                const double cosTheta = ptm::go_min(-(ux * nx + uy * ny + uz * nz), 1.0);
-                                const double sinTheta = ptm::f_sqrt(1.0 - cosTheta * cosTheta);
-                                const bool cannot = ratio * sinTheta > 1.0;
-                                double r0 = (1 - ratio) / (1 + ratio);
-                                r0 = r0 * r0;
-                                const double reflectProb = r0 + (1 - r0) * ptm::go_pow5(1 - cosTheta);
-                                bool reflects = cannot;
-                                if (!cannot) {  // Go's || short-circuit: the draw happens only here
-                                    PT_DRAW(xi)
-                                    reflects = reflectProb > xi;
-                                }
-                                if (!reflects) {  // refractVec, math.go:48-64
-                                    const double ct = ptm::go_min(-ux * nx - uy * ny - uz * nz, 1.0);
-                                    double qx = ux + nx * ct, qy = uy + ny * ct, qz = uz + nz * ct;
-                                    qx *= ratio; qy *= ratio; qz *= ratio;
-                                    const double perpLenSq = qx * qx + qy * qy + qz * qz;
-                                    const double par = -ptm::f_sqrt(ptm::f_abs(1.0 - perpLenSq));
-                                    ndx = qx + nx * par; ndy = qy + ny * par; ndz = qz + nz * par;
-                                }
+                                dielectric_scatter<STATS>(m, ff, ux, uy, uz, nx, ny, nz, rfx, rfy, rfz, rs, c_draw, j_draw, ndx, ndy, ndz);
                                 SEC_END(SEC_DIEL)
                             } else {
                                 attx = m.albedo[0]; atty = m.albedo[1]; attz = m.albedo[2];
@@ -1250,7 +1417,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                             // scattered ray starts at the hit point (no offset)
                             ox = px; oy = py; oz = pz;
                             dx = ndx; dy = ndy; dz = ndz;
-                            if (typ == MAT_DIELECTRIC && ff) {
+                            if (!SPLIT && typ == MAT_DIELECTRIC && ff) {
                                 mode = 1;  // renderer.go:316-319: find the way out before roulette
                                 exit_mat = mi;
                                 c_exit++;
@@ -1263,18 +1430,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             } else {
                 // exit search done (renderer.go:352-370); the hit point of the entry is the ray origin
                 SEC_BEGIN(SEC_EXITPOST)
-                if (best >= 0) {
-                    const double px = ox + dx * tmax, py = oy + dy * tmax, pz = oz + dz * tmax;
-                    const double ex = px - ox, ey = py - oy, ez = pz - oz;
-                    const double distance = ptm::f_sqrt(ex * ex + ey * ey + ez * ez);
-                    const DevMat &m = s_mat[exit_mat];
-                    if (m.absorbs) {
-                        attx = ptm::go_exp(-m.absorption[0] * distance);
-                        atty = ptm::go_exp(-m.absorption[1] * distance);
-                        attz = ptm::go_exp(-m.absorption[2] * distance);
-                    }
-                    ox = px; oy = py; oz = pz;
-                }
+                exit_post(s_mat[exit_mat], best, tmax, ox, oy, oz, dx, dy, dz, attx, atty, attz);
                 mode = 0;
                 do_rr = true;
                 SEC_END(SEC_EXITPOST)
@@ -1283,25 +1439,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
             // ------------------------------------------------------------ roulette + advance
             if (do_rr) {
                 SEC_BEGIN(SEC_RR)
-                if (depth <= 3) {  // renderer.go:375-393
-                    const double maxAtt = ptm::go_max(attx, ptm::go_max(atty, attz));
-                    if (maxAtt < 1e-6) {
-                        finished = true;
-                    } else {
-                        const double rrProb = ptm::go_min(maxAtt, 0.95);
-                        PT_DRAW(xi)
-                        if (xi > rrProb) {
-                            finished = true;
-                        } else {
-                            attx /= rrProb; atty /= rrProb; attz /= rrProb;
-                        }
-                    }
-                }
-                if (!finished) {
-                    Tx *= attx; Ty *= atty; Tz *= attz;
-                    depth--;
-                    if (depth <= 0) finished = true;  // renderer.go:287-289 contributes zero
-                }
+                finished = roulette_advance<STATS>(depth, attx, atty, attz, Tx, Ty, Tz, rs, c_draw, j_draw);
                 SEC_END(SEC_RR)
             }
 
@@ -1309,17 +1447,64 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
                 SEC_BEGIN(SEC_FINISH)
                 // one whole 32-byte record per job: lanes finish at different times, so a [3][njobs] layout
                 // would dirty three partly written sectors per job
-                reinterpret_cast<double4 *>(B.L)[job] = make_double4(Tx * termx, Ty * termy, Tz * termz, 0.0);
+                const auto kb = &KA->B;
+                reinterpret_cast<double4 *>(kb->L)[job] = make_double4(Tx * termx, Ty * termy, Tz * termz, 0.0);
                 if (STATS) {
-                    B.job_seg[job] = j_seg;
-                    B.job_draw[job] = j_draw;
+                    kb->job_seg[job] = j_seg;
+                    kb->job_draw[job] = j_draw;
                 }
                 active = false;
+                if (SPLIT) c_fin++;
                 SEC_END(SEC_FINISH)
+            }
+        }
+        if (SPLIT) {
+            // ---------------------------------------------------------------- dielectric hits leave for the glass queue
+            const uint64_t pm = __ballot(to_glass);
+            if (pm != 0) {
+                const auto gq = &KA->B.glass;
+                const uint32_t np = (uint32_t)__popcll(pm), room = g_end - g_cur;
+                uint32_t nbase = 0;
+                if (np > room) {  // the first `room` lanes fill the old window, the others start a new one
+                    if (lane == 0) nbase = atomicAdd(gq->count, (uint32_t)PT_QUEUE_BLOCK);
+                    nbase = __builtin_amdgcn_readfirstlane(nbase);
+                }
+                const uint32_t rank = lane_rank(pm);
+                const uint32_t slot = rank < room ? g_cur + rank : nbase + (rank - room);
+                if (np > room) {
+                    g_cur = nbase + (np - room);
+                    g_end = nbase + PT_QUEUE_BLOCK;
+                } else {
+                    g_cur += np;
+                }
+                if (to_glass) {
+                    const size_t qc = gq->cap;
+                    gq->d[slot] = ox;
+                    gq->d[qc + slot] = oy;
+                    gq->d[2 * qc + slot] = oz;
+                    gq->d[3 * qc + slot] = dx;
+                    gq->d[4 * qc + slot] = dy;
+                    gq->d[5 * qc + slot] = dz;
+                    gq->d[6 * qc + slot] = Tx;
+                    gq->d[7 * qc + slot] = Ty;
+                    gq->d[8 * qc + slot] = Tz;
+                    gq->d[9 * qc + slot] = tmax;
+                    gq->rs[slot] = rs;
+                    gq->job[slot] = job;
+                    gq->depth[slot] = depth;
+                    gq->best[slot] = best;
+                    if (STATS) { gq->jseg[slot] = j_seg; gq->jdraw[slot] = j_draw; }
+                    active = false;
+                    c_glass++;
+                }
             }
         }
         SEC_END(SEC_ITER)
     }
+    if (SPLIT) {  // what is left of this wave's window stays empty
+        for (uint32_t s = g_cur + lane; s < g_end; s += PT_WAVE) B.glass.job[s] = PT_HOLE;
+    }
+#undef KA
 #undef PT_DRAW
 #undef SEC_BEGIN
 #undef SEC_END
@@ -1342,6 +1527,194 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const DevFrame F, const
         atomicAdd(&B.counters[3], (unsigned long long)w_samples);
     }
     if (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_BVH || SCAN == SCAN_VERIFY_WIDE) {
+        const uint32_t w_mis = wave_sum(c_mismatch);
+        if (lane == 0 && w_mis) atomicAdd(&B.counters[4], (unsigned long long)w_mis);
+    }
+    if (SPLIT) {
+        const uint32_t w_glass = wave_sum(c_glass), w_fin = wave_sum(c_fin), w_contin = wave_sum(c_contin);
+        if (lane == 0) {
+            if (w_glass) atomicAdd(&B.counters[5], (unsigned long long)w_glass);
+            if (w_fin) atomicAdd(&B.counters[18], (unsigned long long)w_fin);
+            if (w_contin) atomicAdd(&B.counters[7], (unsigned long long)w_contin);
+        }
+    }
+}
+
+// The dielectric bounce of every path in the glass queue, all lanes on the same branch: hit record
+// (objects.go:63-88, :181-221), material.scatter for glass (materials.go:162-200), the exit search over the
+// dielectric objects (renderer.go:316-349) with its epilogue (renderer.go:352-370), Russian roulette and the step
+// to the next level (renderer.go:375-403).  Paths that go on are appended to the continuation queue, paths that end
+// write their radiance record (always zero here: glass emits nothing).  One entry per lane, grid-stride.
+// VERIFY: the exit search is also done by the plain object-by-object loop and disagreements are counted.
+template <bool STATS, bool VERIFY>
+__global__ __launch_bounds__(PT_BLOCK) void glass_kernel(const DevFrame F, const TraceBuffers B) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    DevObj *lds_obj = reinterpret_cast<DevObj *>(smem);
+    DevMat *lds_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
+    int *lds_kidx = reinterpret_cast<int *>(smem + (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat));
+    {
+        const uint64_t *g0 = reinterpret_cast<const uint64_t *>(B.objs);
+        uint64_t *l0 = reinterpret_cast<uint64_t *>(lds_obj);
+        const int n0 = F.nobj * (int)(sizeof(DevObj) / 8);
+        for (int i = threadIdx.x; i < n0; i += PT_BLOCK) l0[i] = g0[i];
+        const uint64_t *g1 = reinterpret_cast<const uint64_t *>(B.mats);
+        uint64_t *l1 = reinterpret_cast<uint64_t *>(lds_mat);
+        const int n1 = F.nmat * (int)(sizeof(DevMat) / 8);
+        for (int i = threadIdx.x; i < n1; i += PT_BLOCK) l1[i] = g1[i];
+        for (int i = threadIdx.x; i < F.n_dsph; i += PT_BLOCK) lds_kidx[i] = B.bsph_diel[i].index;
+        for (int i = threadIdx.x; i < F.n_dbox; i += PT_BLOCK) lds_kidx[F.n_dsph + i] = B.bbox_diel[i].index;
+        __syncthreads();
+    }
+    typedef const DevObj __attribute__((address_space(4))) *ConstObjPtr;
+    typedef const BroadSphere __attribute__((address_space(4))) *ConstSphPtr;
+    typedef const BroadBox __attribute__((address_space(4))) *ConstBoxPtr;
+    typedef const int32_t __attribute__((address_space(4))) *ConstIdxPtr;
+    const ConstObjPtr g_obj = (ConstObjPtr)(B.objs);
+    const ConstIdxPtr g_pl = (ConstIdxPtr)(B.plane_idx);
+    const uint32_t all_s = F.n_dsph >= 32 ? 0xffffffffu : ((1u << F.n_dsph) - 1u), all_b = F.n_dbox >= 32 ? 0xffffffffu : ((1u << F.n_dbox) - 1u);
+    const BroadLists<ConstSphPtr, ConstBoxPtr> BL{(ConstSphPtr)B.bsph_diel, (ConstBoxPtr)B.bbox_diel, F.n_dsph, F.n_dbox, all_s, all_b,
+                                                  all_s, all_b, lds_kidx, lds_kidx + F.n_dsph};
+    const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
+    typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
+    const uint32_t n = *(ConstU32Ptr)(B.glass.count);
+    uint32_t c_exit = 0, c_draw = 0, c_mismatch = 0, c_cont = 0;
+    const size_t qg = B.glass.cap, qc = B.cont.cap;
+    uint32_t q_cur = 0, q_end = 0;  // this wave's window of continuation slots (see trace_kernel: one atomic per window)
+
+    for (uint32_t i0 = blockIdx.x * PT_BLOCK + (threadIdx.x & ~(PT_WAVE - 1u)); i0 < n; i0 += gridDim.x * PT_BLOCK) {
+        const uint32_t i = i0 + lane;
+        const bool live = i < n && B.glass.job[i] != PT_HOLE;
+        bool go_on = false;
+        double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, Tx = 0, Ty = 0, Tz = 0;
+        uint64_t rs = 0;
+        uint32_t job = 0, j_seg = 0, j_draw = 0;
+        int depth = 0;
+        if (live) {
+            ox = B.glass.d[i]; oy = B.glass.d[qg + i]; oz = B.glass.d[2 * qg + i];
+            dx = B.glass.d[3 * qg + i]; dy = B.glass.d[4 * qg + i]; dz = B.glass.d[5 * qg + i];
+            Tx = B.glass.d[6 * qg + i]; Ty = B.glass.d[7 * qg + i]; Tz = B.glass.d[8 * qg + i];
+            const double tmax = B.glass.d[9 * qg + i];
+            rs = B.glass.rs[i];
+            job = B.glass.job[i];
+            depth = B.glass.depth[i];
+            const int best = B.glass.best[i];
+            if (STATS) { j_seg = B.glass.jseg[i]; j_draw = B.glass.jdraw[i]; }
+
+            // hit record of the winner
+            const DevObj &o = lds_obj[best];
+            const int kind = o.kind & 0xff;
+            const double px = ox + dx * tmax, py = oy + dy * tmax, pz = oz + dz * tmax;
+            double nx, ny, nz;
+            outward_normal(o, kind, px, py, pz, nx, ny, nz);
+            const bool ff = (dx * nx + dy * ny + dz * nz) < 0;
+            if (!ff) { nx = -nx; ny = -ny; nz = -nz; }
+            const int mi = o.mat;
+            const DevMat &m = lds_mat[mi];
+            bool finished = false;
+            // materials.go:175-182
+            const double dirLen = ptm::f_sqrt(dx * dx + dy * dy + dz * dz);
+            if (dirLen == 0) {
+                finished = true;  // scatter fails -> emitted (0)
+            } else {
+                const double invLen = 1.0 / dirLen;
+                const double ux = dx * invLen, uy = dy * invLen, uz = dz * invLen;
+                double rfx, rfy, rfz;
+                reflect_vec(ux, uy, uz, nx, ny, nz, rfx, rfy, rfz);
+                double ndx, ndy, ndz;
+                dielectric_scatter<STATS>(m, ff, ux, uy, uz, nx, ny, nz, rfx, rfy, rfz, rs, c_draw, j_draw, ndx, ndy, ndz);
+                // scattered ray starts at the hit point (no offset)
+                ox = px; oy = py; oz = pz;
+                dx = ndx; dy = ndy; dz = ndz;
+                double attx = 1, atty = 1, attz = 1;
+                if (ff) {  // renderer.go:316-371: the way out, before roulette
+                    c_exit++;
+                    const RayD ray{ox, oy, oz, dx, dy, dz};
+                    const ProfHooks ph{nullptr, nullptr, nullptr, lane, nullptr};
+                    int ebest = -1;
+                    double etmax = 0;
+                    // same guards as the trace kernel: untamed or far-away rays take the reference's plain loop
+                    const double a_ = dx * dx + dy * dy + dz * dz;
+                    const Clip clip = clip_ray(F, ray, 0.0001);
+                    const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) && (ptm::f_abs(oy) <= 1e100) &&
+                                      (ptm::f_abs(oz) <= 1e100) && !clip.far;
+                    if (__ballot(!tame) != 0) {
+                        scan_uniform(F, g_obj, ray, 1, ebest, etmax);
+                    } else {
+                        scan_broad_narrow<false, VERIFY, 1>(F, g_obj, BL, g_pl, lds_obj, ray, clip, 1, ebest, etmax, ph);
+                        if (VERIFY) {
+                            int best2;
+                            double tmax2;
+                            scan_uniform(F, g_obj, ray, 1, best2, tmax2);
+                            if (ebest != best2 || (ebest >= 0 && !(etmax == tmax2))) {
+                                c_mismatch++;
+                                unsigned long long *dbg = B.counters + 8;
+                                dbg[0] = ((unsigned long long)(uint32_t)ebest << 32) | (uint32_t)best2;
+                                dbg[1] = ptm::to_bits(etmax);
+                                dbg[2] = ptm::to_bits(tmax2);
+                                dbg[3] = 1ull;
+                                dbg[4] = ptm::to_bits(ox); dbg[5] = ptm::to_bits(oy); dbg[6] = ptm::to_bits(oz);
+                                dbg[7] = ptm::to_bits(dx); dbg[8] = ptm::to_bits(dy); dbg[9] = ptm::to_bits(dz);
+                            }
+                            ebest = best2;
+                            etmax = tmax2;
+                        }
+                    }
+                    exit_post(m, ebest, etmax, ox, oy, oz, dx, dy, dz, attx, atty, attz);
+                }
+                finished = roulette_advance<STATS>(depth, attx, atty, attz, Tx, Ty, Tz, rs, c_draw, j_draw);
+            }
+            if (finished) {
+                reinterpret_cast<double4 *>(B.L)[job] = make_double4(Tx * 0.0, Ty * 0.0, Tz * 0.0, 0.0);
+                if (STATS) {
+                    B.job_seg[job] = j_seg;
+                    B.job_draw[job] = j_draw;
+                }
+            } else {
+                go_on = true;
+            }
+        }
+        const uint64_t pm = __ballot(go_on);
+        if (pm != 0) {
+            const uint32_t np = (uint32_t)__popcll(pm), room = q_end - q_cur;
+            uint32_t nbase = 0;
+            if (np > room) {
+                if (lane == 0) nbase = atomicAdd(B.cont.count, (uint32_t)PT_CONT_BLOCK);
+                nbase = __builtin_amdgcn_readfirstlane(nbase);
+            }
+            const uint32_t rank = lane_rank(pm);
+            const uint32_t slot = rank < room ? q_cur + rank : nbase + (rank - room);
+            if (np > room) {
+                q_cur = nbase + (np - room);
+                q_end = nbase + PT_CONT_BLOCK;
+            } else {
+                q_cur += np;
+            }
+            if (go_on) {
+                B.cont.d[slot] = ox;
+                B.cont.d[qc + slot] = oy;
+                B.cont.d[2 * qc + slot] = oz;
+                B.cont.d[3 * qc + slot] = dx;
+                B.cont.d[4 * qc + slot] = dy;
+                B.cont.d[5 * qc + slot] = dz;
+                B.cont.d[6 * qc + slot] = Tx;
+                B.cont.d[7 * qc + slot] = Ty;
+                B.cont.d[8 * qc + slot] = Tz;
+                B.cont.rs[slot] = rs;
+                B.cont.job[slot] = job;
+                B.cont.depth[slot] = depth;
+                if (STATS) { B.cont.jseg[slot] = j_seg; B.cont.jdraw[slot] = j_draw; }
+                c_cont++;
+            }
+        }
+    }
+    for (uint32_t s = q_cur + lane; s < q_end; s += PT_WAVE) B.cont.job[s] = PT_HOLE;  // the rest of the window stays empty
+    const uint32_t w_exit = wave_sum(c_exit), w_draw = wave_sum(c_draw), w_cont = wave_sum(c_cont);
+    if (lane == 0) {
+        if (w_exit) atomicAdd(&B.counters[1], (unsigned long long)w_exit);
+        if (w_draw) atomicAdd(&B.counters[2], (unsigned long long)w_draw);
+        if (w_cont) atomicAdd(&B.counters[6], (unsigned long long)w_cont);
+    }
+    if (VERIFY) {
         const uint32_t w_mis = wave_sum(c_mismatch);
         if (lane == 0 && w_mis) atomicAdd(&B.counters[4], (unsigned long long)w_mis);
     }

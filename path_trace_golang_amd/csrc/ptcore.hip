@@ -95,11 +95,19 @@ struct Device {
     DevBuf<uint8_t> tiles_rgba;
     DevBuf<double> tiles_accum;
     DevBuf<uint32_t> tiles_seg, tiles_draw;
-    DevBuf<unsigned int> queue;
+    DevBuf<unsigned int> queue;       // [0] item cursor of the running trace pass, [1] glass count, [2],[3] continuation counts (ping-pong), [4] always 0
+    DevBuf<BroadSphere> bsph_diel;    // broad-phase records of the dielectric objects only
+    DevBuf<BroadBox> bbox_diel;
+    // path-state queues of the split passes (one entry per job of a chunk at most)
+    DevBuf<double> gq_d, cq_d;
+    DevBuf<unsigned long long> gq_rs, cq_rs;
+    DevBuf<uint32_t> gq_u32, cq_u32;  // job, depth, best, jseg, jdraw planes
+    size_t q_cap = 0;
     DevBuf<unsigned long long> counters;
     DevBuf<unsigned long long> prof;
-    std::vector<EventPair> ev_trace, ev_resolve, ev_raygen;
-    size_t n_trace = 0, n_resolve = 0, n_raygen = 0;
+    std::vector<EventPair> ev_trace, ev_resolve, ev_raygen, ev_glass;
+    size_t n_trace = 0, n_resolve = 0, n_raygen = 0, n_glass = 0;
+    std::vector<char> trace_is_split;  // per trace launch of the frame: the split form?
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     bool first_recorded = false;
     // frame state
@@ -107,7 +115,7 @@ struct Device {
     int32_t nlocal = 0;
     uint32_t nslots = 0;
     bool acc_started = false;
-    int blocks_per_cu = 0;
+    int blocks_per_cu = 0, blocks_per_cu_split = 0, blocks_per_cu_glass = 0;
     uint64_t scene_gen = 0;  // SceneData generation resident on this device (0 = none)
 };
 
@@ -123,6 +131,9 @@ struct Frame {
     uint32_t chunk = 0;
     bool stats_on = false;
     size_t lds_bytes = 0;
+    size_t glass_lds_bytes = 0;
+    int split_rounds = 0;  // trace + glass pass pairs before the all-in-one pass (0: all-in-one only)
+    bool has_glass = false;  // some object is dielectric
     int scan = 0;  // ptk::SCAN_* used for this frame
     std::chrono::steady_clock::time_point t0;
 };
@@ -138,12 +149,15 @@ struct SceneData {
     std::vector<DevMat> mats;
     std::vector<BroadSphere> bsph;
     std::vector<BroadBox> bbox;
+    std::vector<BroadSphere> bsph_diel;
+    std::vector<BroadBox> bbox_diel;
     std::vector<int32_t> plane_idx;
     std::vector<BvhNode> bvh_nodes;
     std::vector<BvhObj> bvh_objs;
     int bvh_depth = 0;
     int bvh_stack_need = 0;
     size_t lds_bytes = 0;
+    size_t glass_lds_bytes = 0;
     int scan = 0;
     DevFrame Fs{};  // the scene-dependent fields of DevFrame
 };
@@ -161,7 +175,8 @@ struct pt_ctx {
     DevBuf<uint8_t> f_rgba;
     DevBuf<double> f_accum;
     DevBuf<uint32_t> f_seg, f_draw;
-    size_t l_budget_bytes = (size_t)16 << 30;  // per-chunk job buffers (radiance + primary rays): 5.5 % of the 288 GB
+    size_t l_budget_bytes = (size_t)48 << 30;  // per-chunk job buffers (radiance, primary rays, path-state queues): a sixth of the 288 GB
+    int split_rounds = 2;  // PTCORE_SPLIT_ROUNDS: trace + glass pass pairs per chunk before the all-in-one pass (bitmask scan only)
     uint32_t claim = 256;
     int max_blocks_per_cu = 8;
     int scan_mode = -1;  // -1 = choose by scene size; PTCORE_SCAN=uniform|broad|verify|bvh|verify_bvh forces one
@@ -198,6 +213,16 @@ DevMat convert_material(const pt_material &m) {  // materials.go:28-55
             r.typ = MAT_DIELECTRIC;
             for (int i = 0; i < 3; i++) { r.albedo[i] = m.albedo[i]; r.absorption[i] = m.absorption[i]; }
             r.ior = ior;
+            // reflectance's r0 for both faces (materials.go:183, :226-229): the reference recomputes these on every hit
+            // from the same operands; done once here with the same IEEE operations (this file is built with
+            // -ffp-contract=off like the kernels)
+            r.inv_ior = 1.0 / ior;
+            {
+                double a = (1 - r.inv_ior) / (1 + r.inv_ior);
+                r.r0_front = a * a;
+                double b = (1 - ior) / (1 + ior);
+                r.r0_back = b * b;
+            }
             break;
         }
         case PT_MAT_EMISSIVE:
@@ -334,6 +359,8 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     DevFrame &F = fr.Fs;
     fr.bsph.clear();
     fr.bbox.clear();
+    fr.bsph_diel.clear();
+    fr.bbox_diel.clear();
     fr.plane_idx.clear();
     F.sph_all = F.box_all = F.sph_diel = F.box_diel = 0;
     double B = 1.0;
@@ -361,18 +388,27 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
             s.diel = (o.kind & 0x100) ? 1 : 0;
             if (fr.bsph.size() < 32 && (o.kind & 0x100)) F.sph_diel |= 1u << fr.bsph.size();
             fr.bsph.push_back(s);
+            if (o.kind & 0x100) fr.bsph_diel.push_back(s);
         } else if (kind == KIND_BOX) {
             BroadBox b;
             std::memset(&b, 0, sizeof b);
             for (int k = 0; k < 3; k++) {
                 const double lo = std::min(o.a[k], o.b[k]) - m, hi = std::max(o.a[k], o.b[k]) + m;
-                b.lo[k] = (lo == lo) ? round_down_f(lo) : -INFINITY;
-                b.hi[k] = (hi == hi) ? round_up_f(hi) : INFINITY;
+                const float c = (float)(0.5 * lo + 0.5 * hi);
+                if (lo == lo && hi == hi && std::isfinite(c)) {
+                    b.c[k] = c;
+                    b.h[k] = round_up_f(std::max((double)c - lo, hi - (double)c));  // [c - h, c + h] holds [lo, hi]
+                    if (!(b.h[k] == b.h[k])) b.h[k] = INFINITY;
+                } else {  // absurd or non-finite bounds: this slab constrains nothing
+                    b.c[k] = 0.0f;
+                    b.h[k] = INFINITY;
+                }
             }
             b.index = (int32_t)i;
             b.diel = (o.kind & 0x100) ? 1 : 0;
             if (fr.bbox.size() < 32 && (o.kind & 0x100)) F.box_diel |= 1u << fr.bbox.size();
             fr.bbox.push_back(b);
+            if (o.kind & 0x100) fr.bbox_diel.push_back(b);
         } else {
             fr.plane_idx.push_back((int32_t)i);
         }
@@ -380,6 +416,8 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     F.n_bsph = (int32_t)fr.bsph.size();
     F.n_bbox = (int32_t)fr.bbox.size();
     F.n_plane = (int32_t)fr.plane_idx.size();
+    F.n_dsph = (int32_t)fr.bsph_diel.size();
+    F.n_dbox = (int32_t)fr.bbox_diel.size();
     F.broad_ok = (fr.bsph.size() <= 32 && fr.bbox.size() <= 32) ? 1 : (fr.bsph.size() <= 128 && fr.bbox.size() <= 128) ? 2 : 0;
     F.sph_all = fr.bsph.size() >= 32 ? 0xffffffffu : ((1u << fr.bsph.size()) - 1u);
     F.box_all = fr.bbox.size() >= 32 ? 0xffffffffu : ((1u << fr.bbox.size()) - 1u);
@@ -409,26 +447,38 @@ int32_t validate(const pt_scene *scene, const pt_config *cfg) {
 
 // ---------------------------------------------------------------- per-device frame
 
-using TraceFn = void (*)(const DevFrame, const DevSky, const TraceBuffers);
+using TraceFn = void (*)(const TraceArgs);
 
-// The shipping instantiations are <false,false,*>; STATS adds per-pixel counters, PROF the section profile.
-TraceFn pick_trace(bool stats, bool prof, int scan) {
+// The shipping instantiations are <false,false,*,*>; STATS adds per-pixel counters, PROF the section profile.
+// split: the form whose dielectric hits leave for the glass queue (bitmask scan of the reference-sized scenes only).
+TraceFn pick_trace(bool stats, bool prof, int scan, bool split = false) {
     using namespace ptk;
     if (prof) {
-        if (scan == SCAN_UNIFORM) return trace_kernel<false, true, SCAN_UNIFORM>;
-        if (scan == SCAN_BVH || scan == SCAN_VERIFY_BVH) return trace_kernel<false, true, SCAN_BVH>;
-        if (scan == SCAN_BROAD_WIDE || scan == SCAN_VERIFY_WIDE) return trace_kernel<false, true, SCAN_BROAD_WIDE>;
-        return trace_kernel<false, true, SCAN_BROAD>;
+        if (scan == SCAN_UNIFORM) return trace_kernel<false, true, SCAN_UNIFORM, false>;
+        if (scan == SCAN_BVH || scan == SCAN_VERIFY_BVH) return trace_kernel<false, true, SCAN_BVH, false>;
+        if (scan == SCAN_BROAD_WIDE || scan == SCAN_VERIFY_WIDE) return trace_kernel<false, true, SCAN_BROAD_WIDE, false>;
+        return split ? trace_kernel<false, true, SCAN_BROAD, true> : trace_kernel<false, true, SCAN_BROAD, false>;
+    }
+    if (split) {
+        if (scan == SCAN_VERIFY) return stats ? trace_kernel<true, false, SCAN_VERIFY, true> : trace_kernel<false, false, SCAN_VERIFY, true>;
+        return stats ? trace_kernel<true, false, SCAN_BROAD, true> : trace_kernel<false, false, SCAN_BROAD, true>;
     }
     switch (scan) {
-        case SCAN_BROAD: return stats ? trace_kernel<true, false, SCAN_BROAD> : trace_kernel<false, false, SCAN_BROAD>;
-        case SCAN_VERIFY: return stats ? trace_kernel<true, false, SCAN_VERIFY> : trace_kernel<false, false, SCAN_VERIFY>;
-        case SCAN_BROAD_WIDE: return stats ? trace_kernel<true, false, SCAN_BROAD_WIDE> : trace_kernel<false, false, SCAN_BROAD_WIDE>;
-        case SCAN_VERIFY_WIDE: return stats ? trace_kernel<true, false, SCAN_VERIFY_WIDE> : trace_kernel<false, false, SCAN_VERIFY_WIDE>;
-        case SCAN_BVH: return stats ? trace_kernel<true, false, SCAN_BVH> : trace_kernel<false, false, SCAN_BVH>;
-        case SCAN_VERIFY_BVH: return stats ? trace_kernel<true, false, SCAN_VERIFY_BVH> : trace_kernel<false, false, SCAN_VERIFY_BVH>;
-        default: return stats ? trace_kernel<true, false, SCAN_UNIFORM> : trace_kernel<false, false, SCAN_UNIFORM>;
+        case SCAN_BROAD: return stats ? trace_kernel<true, false, SCAN_BROAD, false> : trace_kernel<false, false, SCAN_BROAD, false>;
+        case SCAN_VERIFY: return stats ? trace_kernel<true, false, SCAN_VERIFY, false> : trace_kernel<false, false, SCAN_VERIFY, false>;
+        case SCAN_BROAD_WIDE: return stats ? trace_kernel<true, false, SCAN_BROAD_WIDE, false> : trace_kernel<false, false, SCAN_BROAD_WIDE, false>;
+        case SCAN_VERIFY_WIDE: return stats ? trace_kernel<true, false, SCAN_VERIFY_WIDE, false> : trace_kernel<false, false, SCAN_VERIFY_WIDE, false>;
+        case SCAN_BVH: return stats ? trace_kernel<true, false, SCAN_BVH, false> : trace_kernel<false, false, SCAN_BVH, false>;
+        case SCAN_VERIFY_BVH: return stats ? trace_kernel<true, false, SCAN_VERIFY_BVH, false> : trace_kernel<false, false, SCAN_VERIFY_BVH, false>;
+        default: return stats ? trace_kernel<true, false, SCAN_UNIFORM, false> : trace_kernel<false, false, SCAN_UNIFORM, false>;
     }
+}
+
+using GlassFn = void (*)(const DevFrame, const TraceBuffers);
+GlassFn pick_glass(bool stats, int scan) {
+    using namespace ptk;
+    if (scan == SCAN_VERIFY) return stats ? glass_kernel<true, true> : glass_kernel<false, true>;
+    return stats ? glass_kernel<true, false> : glass_kernel<false, false>;
 }
 
 int32_t dev_events(Device &d, std::vector<EventPair> &v, size_t need) {
@@ -453,7 +503,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
     d.nlocal = tiles_of_shard(fr.ntx * fr.nty, shard);
     d.nslots = (uint32_t)d.nlocal * 1024u;
     d.acc_started = false;
-    d.n_trace = d.n_resolve = d.n_raygen = 0;
+    d.n_trace = d.n_resolve = d.n_raygen = d.n_glass = 0;
     d.first_recorded = false;
     if (d.scene_gen != sd.gen) {
         HIP_TRY(d.objs.reserve(std::max<size_t>(1, world.size())));
@@ -470,6 +520,12 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
             HIP_TRY(hipMemcpyAsync(d.bbox.p, sd.bbox.data(), sd.bbox.size() * sizeof(BroadBox), hipMemcpyHostToDevice, d.stream));
         if (!sd.plane_idx.empty())
             HIP_TRY(hipMemcpyAsync(d.plane_idx.p, sd.plane_idx.data(), sd.plane_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(d.bsph_diel.reserve(std::max<size_t>(1, sd.bsph_diel.size())));
+        HIP_TRY(d.bbox_diel.reserve(std::max<size_t>(1, sd.bbox_diel.size())));
+        if (!sd.bsph_diel.empty())
+            HIP_TRY(hipMemcpyAsync(d.bsph_diel.p, sd.bsph_diel.data(), sd.bsph_diel.size() * sizeof(BroadSphere), hipMemcpyHostToDevice, d.stream));
+        if (!sd.bbox_diel.empty())
+            HIP_TRY(hipMemcpyAsync(d.bbox_diel.p, sd.bbox_diel.data(), sd.bbox_diel.size() * sizeof(BroadBox), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(d.bvh_nodes.reserve(std::max<size_t>(1, sd.bvh_nodes.size())));
         HIP_TRY(d.bvh_objs.reserve(std::max<size_t>(1, sd.bvh_objs.size())));
         if (!sd.bvh_nodes.empty())
@@ -479,7 +535,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         HIP_TRY(hipStreamSynchronize(d.stream));
         d.scene_gen = sd.gen;
     }
-    HIP_TRY(d.queue.reserve(1));
+    HIP_TRY(d.queue.reserve(8));
     HIP_TRY(d.counters.reserve(24));
     HIP_TRY(hipMemsetAsync(d.counters.p, 0, 24 * sizeof(unsigned long long), d.stream));
     if (ctx->profile_sections) {
@@ -502,10 +558,23 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         if (e == hipSuccess) e = d.ray_ndraw.reserve(njobs_max);
         if (e == hipSuccess && fr.stats_on) e = d.job_seg.reserve(njobs_max);
         if (e == hipSuccess && fr.stats_on) e = d.job_draw.reserve(njobs_max);
+        if (fr.split_rounds > 0 && fr.has_glass) {  // path-state queues: 10 doubles + stream state + job, depth, hit object (+ 2 counters) per entry, twice
+            // one entry per job at most, plus the slots the waves of a trace pass reserve in blocks and may leave empty
+            const size_t qcap = njobs_max + (size_t)d.num_cu * 32u * PT_CONT_BLOCK;
+            const size_t planes = fr.stats_on ? 5 : 3;
+            if (e == hipSuccess) e = d.gq_d.reserve(10 * qcap);
+            if (e == hipSuccess) e = d.cq_d.reserve(10 * qcap);
+            if (e == hipSuccess) e = d.gq_rs.reserve(qcap);
+            if (e == hipSuccess) e = d.cq_rs.reserve(qcap);
+            if (e == hipSuccess) e = d.gq_u32.reserve(planes * qcap);
+            if (e == hipSuccess) e = d.cq_u32.reserve(planes * qcap);
+            d.q_cap = qcap;
+        }
         if (e == hipSuccess) break;
         (void)hipGetLastError();
         if (e != hipErrorOutOfMemory || fr.chunk <= 1) return fail(PT_ERR_HIP, std::string("job buffers: ") + hipGetErrorString(e));
         d.L.release(); d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release(); d.job_seg.release(); d.job_draw.release();
+        d.gq_d.release(); d.cq_d.release(); d.gq_rs.release(); d.cq_rs.release(); d.gq_u32.release(); d.cq_u32.release();
         fr.chunk = std::max<uint32_t>(1, fr.chunk / 2);
         if (std::getenv("PTCORE_VERBOSE")) std::fprintf(stderr, "ptcore: device %d is short of memory, samples per pass reduced to %u\n", d.ordinal, fr.chunk);
     }
@@ -518,6 +587,14 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
     int nb = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan), PT_BLOCK, lds));
     d.blocks_per_cu = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
+    d.blocks_per_cu_split = d.blocks_per_cu;
+    d.blocks_per_cu_glass = 1;
+    if (fr.split_rounds > 0) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, true), PT_BLOCK, lds));
+        d.blocks_per_cu_split = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_glass(fr.stats_on, fr.scan), PT_BLOCK, fr.glass_lds_bytes));
+        d.blocks_per_cu_glass = std::max(1, std::min(nb, 8));
+    }
     return PT_OK;
 }
 
@@ -552,18 +629,42 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     B.counters = d.counters.p;
     B.prof = ctx->profile_sections ? d.prof.p : nullptr;
 
-    if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + 1)) return rc;
+    const int rounds = fr.split_rounds;
+    if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + (size_t)rounds + 1)) return rc;
+    if (int32_t rc = dev_events(d, d.ev_glass, d.n_glass + (size_t)rounds + 1)) return rc;
     if (int32_t rc = dev_events(d, d.ev_resolve, d.n_resolve + 1)) return rc;
     if (!d.first_recorded) {
         HIP_TRY(hipEventRecord(d.ev_first, d.stream));
         d.first_recorded = true;
     }
-    {  // ray generation, then the trace kernel (which also handles max_depth <= 0: black samples, camera draws counted)
-        HIP_TRY(hipMemsetAsync(d.queue.p, 0, sizeof(unsigned int), d.stream));
+    // queue words: [0] item cursor of the running trace pass, [1] glass entries, [2],[3] continuation entries (one is
+    // read by a trace pass while glass_kernel fills the other), [4] stays 0 (a first pass starts from no continuations)
+    unsigned int *qw = d.queue.p;
+    B.cont_in = qw + 4;
+    B.bsph_diel = d.bsph_diel.p;
+    B.bbox_diel = d.bbox_diel.p;
+    std::memset(&B.glass, 0, sizeof B.glass);
+    std::memset(&B.cont, 0, sizeof B.cont);
+    if (rounds > 0) {
+        const size_t cap = d.q_cap;
+        auto bind = [&](PathQueue &q, DevBuf<double> &qd, DevBuf<unsigned long long> &qrs, DevBuf<uint32_t> &qu) {
+            q.d = qd.p;
+            q.rs = qrs.p;
+            q.job = qu.p;
+            q.depth = reinterpret_cast<int32_t *>(qu.p + cap);
+            q.best = reinterpret_cast<int32_t *>(qu.p + 2 * cap);
+            q.jseg = fr.stats_on ? qu.p + 3 * cap : nullptr;
+            q.jdraw = fr.stats_on ? qu.p + 4 * cap : nullptr;
+            q.cap = (uint32_t)cap;
+        };
+        bind(B.glass, d.gq_d, d.gq_rs, d.gq_u32);
+        bind(B.cont, d.cq_d, d.cq_rs, d.cq_u32);
+        B.glass.count = qw + 1;
+    }
+    {  // ray generation, then the trace passes (which also handle max_depth <= 0: black samples, camera draws counted)
+        HIP_TRY(hipMemsetAsync(qw, 0, 8 * sizeof(unsigned int), d.stream));
         const size_t lds = fr.lds_bytes;
         const uint32_t waves_needed = (F.njobs + 63u) / 64u;
-        uint32_t grid = (uint32_t)(d.num_cu * d.blocks_per_cu);
-        grid = std::max(1u, std::min(grid, (waves_needed + 3u) / 4u));
         if (int32_t rc = dev_events(d, d.ev_raygen, d.n_raygen + 1)) return rc;
         EventPair &eg = d.ev_raygen[d.n_raygen++];
         HIP_TRY(hipEventRecord(eg.a, d.stream));
@@ -571,12 +672,51 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
                            d.ray.p, d.ray_rng.p, d.ray_ndraw.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(eg.b, d.stream));
-        EventPair &e = d.ev_trace[d.n_trace++];
-        HIP_TRY(hipEventRecord(e.a, d.stream));
-        hipLaunchKernelGGL(pick_trace(fr.stats_on, ctx->profile_sections, fr.scan), dim3(grid), dim3(PT_BLOCK), lds, d.stream, F,
-                           fr.sky, B);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e.b, d.stream));
+        auto launch_trace = [&](bool split, bool first) -> int32_t {
+            TraceArgs A;
+            A.F = F;
+            A.F.fresh = first ? F.njobs : 0u;
+            A.sky = fr.sky;
+            A.B = B;
+            uint32_t grid = (uint32_t)(d.num_cu * (split ? d.blocks_per_cu_split : d.blocks_per_cu));
+            if (first) grid = std::min(grid, (waves_needed + 3u) / 4u);  // later passes: the item count lives on the device
+            grid = std::max(1u, grid);
+            if (d.trace_is_split.size() <= d.n_trace) d.trace_is_split.resize(d.n_trace + 1);
+            d.trace_is_split[d.n_trace] = split ? 1 : 0;
+            EventPair &e = d.ev_trace[d.n_trace++];
+            HIP_TRY(hipEventRecord(e.a, d.stream));
+            hipLaunchKernelGGL(pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, split), dim3(grid), dim3(PT_BLOCK), lds, d.stream, A);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(e.b, d.stream));
+            return PT_OK;
+        };
+        if (rounds == 0) {
+            if (int32_t rc = launch_trace(false, true)) return rc;
+        } else {
+            // Split passes: trace (dielectric hits -> glass queue), glass (-> continuation queue), `rounds` times; what is
+            // still under way then (paths with more than `rounds` dielectric bounces) finishes in the all-in-one form.
+            const uint32_t glass_grid = std::max(1u, std::min((uint32_t)(d.num_cu * d.blocks_per_cu_glass), (F.njobs + PT_BLOCK - 1) / PT_BLOCK));
+            for (int r = 0; r < rounds; r++) {
+                if (r > 0) HIP_TRY(hipMemsetAsync(qw, 0, 2 * sizeof(unsigned int), d.stream));  // cursor and glass count
+                unsigned int *c_in = r == 0 ? qw + 4 : qw + 2 + (r & 1), *c_out = qw + 2 + ((r + 1) & 1);
+                HIP_TRY(hipMemsetAsync(c_out, 0, sizeof(unsigned int), d.stream));
+                B.cont_in = c_in;
+                B.cont.count = c_out;
+                if (int32_t rc = launch_trace(true, r == 0)) return rc;
+                if (!fr.has_glass) break;  // nothing can have entered the glass queue: the frame is done
+                EventPair &e = d.ev_glass[d.n_glass++];
+                HIP_TRY(hipEventRecord(e.a, d.stream));
+                hipLaunchKernelGGL(pick_glass(fr.stats_on, fr.scan), dim3(glass_grid), dim3(PT_BLOCK), fr.glass_lds_bytes, d.stream, F, B);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(e.b, d.stream));
+            }
+            if (fr.has_glass) {
+                HIP_TRY(hipMemsetAsync(qw, 0, sizeof(unsigned int), d.stream));
+                B.cont_in = qw + 2 + (rounds & 1);
+                B.cont.count = qw + 5;  // unused by the all-in-one form
+                if (int32_t rc = launch_trace(false, false)) return rc;
+            }
+        }
     }
     ptk::ResolveArgs R;
     std::memset(&R, 0, sizeof R);
@@ -654,14 +794,28 @@ int32_t dev_collect(Device &d, pt_stats *st, int slot) {
     st->exit_scans += c[1];
     st->draws += c[2];
     st->samples += c[3];
+    st->glass_events += c[5];
+    st->continuations += c[6];
+    st->split_cont_in += c[7];
+    st->split_finished += c[18];
     if (d.prof.p && slot == 0)
         HIP_TRY(hipMemcpy(g_profile_scratch, d.prof.p, sizeof g_profile_scratch, hipMemcpyDeviceToHost));
-    double tr = 0, rs = 0;
+    double tr = 0, rs = 0, trs = 0, gl = 0;
     for (size_t i = 0; i < d.n_trace; i++) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d.ev_trace[i].a, d.ev_trace[i].b));
         tr += ms;
+        if (i < d.trace_is_split.size() && d.trace_is_split[i]) trs += ms;
     }
+    for (size_t i = 0; i < d.n_glass; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, d.ev_glass[i].a, d.ev_glass[i].b));
+        gl += ms;
+    }
+    st->glass_ms = std::max(st->glass_ms, gl);
+    st->trace_split_ms = std::max(st->trace_split_ms, trs);
+    st->glass_launches += (int32_t)d.n_glass;
+    for (size_t i = 0; i < d.n_trace && i < d.trace_is_split.size(); i++) st->trace_split_launches += d.trace_is_split[i] ? 1 : 0;
     for (size_t i = 0; i < d.n_resolve; i++) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, d.ev_resolve[i].a, d.ev_resolve[i].b));
@@ -785,6 +939,8 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     sd.lds_bytes = big ? stack_bytes + (size_t)F.bvh_lds_nodes * sizeof(BvhNode)
                        : (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
                              (size_t)(sd.bsph.size() + sd.bbox.size()) * sizeof(int);
+    sd.glass_lds_bytes = (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
+                         (size_t)(sd.bsph_diel.size() + sd.bbox_diel.size()) * sizeof(int);
     if (sd.lds_bytes > 160 * 1024)
         return fail(PT_ERR_INVALID, "scene does not fit the 160 KiB LDS of a CU with this scan strategy (use the BVH: unset PTCORE_SCAN)");
     sd.gen++;
@@ -802,6 +958,13 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     fr.nmat = sd.Fs.nmat;
     fr.scan = sd.scan;
     fr.lds_bytes = sd.lds_bytes;
+    fr.glass_lds_bytes = sd.glass_lds_bytes;
+    fr.has_glass = false;
+    for (const DevObj &o : sd.world) fr.has_glass = fr.has_glass || (o.kind & 0x100);
+    // split passes: the bitmask scan of reference-sized scenes; a path has at most max_depth dielectric bounces
+    fr.split_rounds = 0;
+    if ((sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY) && cfg->max_depth > 0)
+        fr.split_rounds = fr.has_glass ? std::max(0, std::min(ctx->split_rounds, cfg->max_depth)) : (ctx->split_rounds > 0 ? 1 : 0);
     fr.cam = new_camera(scene->camera, cfg->width, cfg->height);
     fr.sky = make_sky(scene->sky);
     fr.ntx = (cfg->width + 31) / 32;
@@ -821,7 +984,9 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     // chunk of samples per pass: bounded by the L budget and by 2^31 jobs
     uint32_t chunk = cfg->spp_chunk > 0 ? (uint32_t)cfg->spp_chunk : 0;
     const uint32_t slots = std::max(1u, max_slots);
-    if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * 90));  // 32 B radiance record + 58 B primary ray per job
+    // per job: 32 B radiance record + 58 B primary ray, and with split passes two path-state queues of 100 B per entry
+    const size_t job_bytes = 90 + (fr.split_rounds > 0 && fr.has_glass ? 200 : 0);
+    if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * job_bytes));
     chunk = std::min<uint32_t>(chunk, (uint32_t)std::max(1, cfg->samples_per_px));
     chunk = std::min<uint32_t>(chunk, std::max(1u, 0x7fffffffu / slots));
     fr.chunk = chunk;
@@ -881,6 +1046,7 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
         else ctx->scan_mode = -1;
     }
     if (const char *e = std::getenv("PTCORE_PROFILE")) ctx->profile_sections = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PTCORE_SPLIT_ROUNDS")) ctx->split_rounds = std::max(0, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("PTCORE_BLOCKS_PER_CU")) {
         long c = std::atol(e);
         if (c >= 1 && c <= 8) ctx->max_blocks_per_cu = (int)c;
@@ -927,6 +1093,9 @@ void pt_destroy(pt_ctx *ctx) {
         d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release();
         d.objs.release(); d.mats.release(); d.bsph.release(); d.bbox.release(); d.plane_idx.release(); d.bvh_nodes.release(); d.bvh_objs.release(); d.L.release(); d.job_seg.release(); d.job_draw.release();
         d.prof.release();
+        d.bsph_diel.release(); d.bbox_diel.release();
+        d.gq_d.release(); d.cq_d.release(); d.gq_rs.release(); d.cq_rs.release(); d.gq_u32.release(); d.cq_u32.release();
+        for (EventPair &e : d.ev_glass) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         d.acc.release(); d.acc_seg.release(); d.acc_draw.release(); d.tiles_rgba.release();
         d.tiles_accum.release(); d.tiles_seg.release(); d.tiles_draw.release(); d.queue.release();
         d.counters.release();

@@ -1,77 +1,90 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/prof_<tag>/ (tools/profile.sh) into profiles/<tag>_*.{csv,json}."""
+"""Condenses gpurun_out/prof_<tag>/ (tools/profile.sh) into profiles/<tag>_*.{csv,json}.
+
+Kernels are grouped by what they are: the split form of the trace kernel ("trace_split", the dominant launches),
+its all-in-one form ("trace_allinone"), glass_kernel, raygen, resolve.  PMC values are summed over all launches
+of a class in the profiled command; HBM bytes = FETCH_SIZE x 2 (gfx950: the counter reports half of a wide
+coalesced read, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KiB units."""
 import csv
 import glob
 import json
 import os
+import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = "gpurun_out/prof_" + tag
 os.makedirs("profiles", exist_ok=True)
 out = {"tag": tag}
+
+
+def klass(name: str):
+    m = re.search(r"trace_kernel<(\w+), (\w+), (\d+), (\w+)>", name)
+    if m:
+        return "trace_split" if m.group(4) == "true" else "trace_allinone"
+    for k in ("glass_kernel", "raygen_kernel", "resolve_kernel", "wf_", "untile_kernel"):
+        if k in name:
+            return k.replace("_kernel", "")
+    return None
+
+
 for f in glob.glob(src + "/trace/**/*_kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     with open("profiles/%s_kernel_stats.csv" % tag, "w") as g:
         g.write(open(f).read())
-    out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage")}
-                           for r in rows[:5]]
-try:
-    out["bench_under_trace"] = json.load(open(src + "/bench_under_trace.json"))
-except Exception as e:  # noqa: BLE001
-    out["bench_under_trace"] = str(e)
+    out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage")} for r in rows[:8]]
+for key in ("bench_under_trace", "pmc3"):
+    try:
+        out[key if key != "pmc3" else "bench_under_pmc"] = json.load(open(src + "/%s.json" % key))
+    except Exception as e:  # noqa: BLE001
+        out[key] = str(e)
+
 pmc = {}
 for f in sorted(glob.glob(src + "/pmc*/**/*_counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"]
-        if "trace_kernel" in name:
-            key = "trace_kernel"
-        elif "resolve_kernel" in name:
-            key = "resolve_kernel"
-        else:
+        k = klass(r["Kernel_Name"])
+        if not k:
             continue
-        pmc.setdefault(key, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-summary = {}
-for k, d in pmc.items():
-    summary[k] = {c: {"per_launch": v} for c, v in d.items()}
-out["pmc"] = summary
-t = pmc.get("trace_kernel", {})
+        d = pmc.setdefault(k, {}).setdefault(r["Counter_Name"], {"sum": 0.0, "launches": 0})
+        d["sum"] += float(r["Counter_Value"])
+        d["launches"] += 1
+out["pmc"] = pmc
 
-
-def g(c):
-    v = t.get(c)
-    return v[0] if v else 0.0  # launch 0 is a full spp chunk, the same shape as every launch of the full run
-
-
-jobs = None
-try:
-    import re
-    b3 = json.load(open(src + "/pmc3.json"))
-    m = re.search(r"(\d+)x(\d+), (\d+) spp", b3["config"]["workload"])
-    jobs = int(m.group(1)) * int(m.group(2)) * min(int(b3["config"]["spp_chunk"]), int(m.group(3)))
-except Exception as e:  # noqa: BLE001
-    out["jobs_error"] = str(e)
-if t:
-    fetch_b = g("FETCH_SIZE") * 1024.0 * 2.0  # KB; x2: gfx950 FETCH_SIZE reports half of a wide coalesced read (guide, HBM section)
+derived = {}
+for k, t in pmc.items():
+    g = lambda c: t.get(c, {}).get("sum", 0.0)  # noqa: E731
+    fetch_b = g("FETCH_SIZE") * 1024.0 * 2.0
     write_b = g("WRITE_SIZE") * 1024.0
-    out["derived_trace_kernel"] = {
+    derived[k] = {
+        "launches": t.get("SQ_WAVES", t.get("FETCH_SIZE", {})).get("launches"),
         "waves": g("SQ_WAVES"),
-        "valu_insts_per_wave": g("SQ_INSTS_VALU") / max(g("SQ_WAVES"), 1),
-        "valu_lane_utilisation": (g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64.0)
-                                  if g("SQ_ACTIVE_INST_VALU") else None),
-        "valu_busy_share_of_wave_cycles": g("SQ_ACTIVE_INST_VALU") / max(g("SQ_WAVE_CYCLES"), 1),
-        "f64_add": g("SQ_INSTS_VALU_ADD_F64"), "f64_mul": g("SQ_INSTS_VALU_MUL_F64"),
-        "f64_fma": g("SQ_INSTS_VALU_FMA_F64"), "f64_trans": g("SQ_INSTS_VALU_TRANS_F64"),
-        "int32": g("SQ_INSTS_VALU_INT32"), "int64": g("SQ_INSTS_VALU_INT64"), "cvt": g("SQ_INSTS_VALU_CVT"),
-        "valu_total": g("SQ_INSTS_VALU"), "salu": g("SQ_INSTS_SALU"), "smem": g("SQ_INSTS_SMEM"),
+        "valu_insts": g("SQ_INSTS_VALU"),
+        "valu_lane_utilisation": (g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64.0) if g("SQ_ACTIVE_INST_VALU") else None),
+        "f64_add": g("SQ_INSTS_VALU_ADD_F64"), "f64_mul": g("SQ_INSTS_VALU_MUL_F64"), "f64_fma": g("SQ_INSTS_VALU_FMA_F64"),
+        "f64_trans": g("SQ_INSTS_VALU_TRANS_F64"), "int32": g("SQ_INSTS_VALU_INT32"), "int64": g("SQ_INSTS_VALU_INT64"),
+        "cvt": g("SQ_INSTS_VALU_CVT"), "salu": g("SQ_INSTS_SALU"), "smem": g("SQ_INSTS_SMEM"), "lds": g("SQ_INSTS_LDS"),
         "hbm_fetch_bytes_x2": fetch_b, "hbm_write_bytes": write_b,
     }
-    json.dump({"trace_kernel": {"hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes_corrected_x2": fetch_b,
-                                "write_bytes": write_b, "samples_in_measured_launch": jobs,
-                                "hbm_bytes_per_sample": (fetch_b + write_b) / jobs if jobs else None,
-                                "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                          "separate passes; FETCH_SIZE doubled per the gfx950 correction)" % tag}},
-              open("profiles/pmc_traffic.json", "w"), indent=1)
+out["derived"] = derived
+
+# HBM bytes per algorithmic byte of the dominant kernel, for bench.py's roofline.traffic
+traffic = {}
+b = out.get("bench_under_pmc")
+if isinstance(b, dict) and "roofline" in b:
+    name = b["roofline"]["kernel"]
+    k = "trace_split" if name.endswith("true>") else "trace_allinone"
+    if k in derived and derived[k]["hbm_fetch_bytes_x2"]:
+        alg = b["roofline"]["alg_bytes_per_launch"] * b["roofline"]["launches_per_step"] * b["steps"]
+        hbm = derived[k]["hbm_fetch_bytes_x2"] + derived[k]["hbm_write_bytes"]
+        traffic[name] = {
+            "hbm_bytes": hbm, "fetch_bytes_corrected_x2": derived[k]["hbm_fetch_bytes_x2"], "write_bytes": derived[k]["hbm_write_bytes"],
+            "algorithmic_bytes": alg, "hbm_bytes_per_alg_byte": hbm / alg if alg else None,
+            "workload": b["config"]["workload"],
+            "source": "profiles/%s_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, all launches of this kernel "
+                      "in the profiled command; FETCH_SIZE doubled per the gfx950 correction)" % tag}
+        json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
+out["pmc_traffic"] = traffic
 json.dump(out, open("profiles/%s_summary.json" % tag, "w"), indent=1)
-print(json.dumps(out.get("derived_trace_kernel"), indent=1))
+print(json.dumps(derived, indent=1))
 print(json.dumps(out.get("kernel_stats"), indent=1))
+print(json.dumps(traffic, indent=1))
