@@ -273,6 +273,12 @@ int32_t pt_debug_profile(pt_ctx *ctx, uint64_t *out, int32_t n);
  * accumulated over every frame finished in this process (0 = the culling never changed a result). */
 int64_t pt_debug_scan_mismatches(pt_ctx *ctx);
 
+/* Diagnostics only: the narrow phase and Russian roulette divide several numerators by one denominator and share the
+ * reciprocal refinement of the IEEE division between them (div_shared in csrc/pt_kernels.h).  Compares that form with
+ * the plain division, bit for bit, on `millions` x 10^6 random and patterned operand pairs on the GPU and returns the
+ * number of pairs that differ (must be 0), or -PT_ERR_* on failure. */
+int64_t pt_debug_div_selftest(pt_ctx *ctx, int32_t millions, uint64_t seed);
+
 /* Diagnostics only, no GPU needed: builds the bounding-volume hierarchy used for scenes with more
  * than 128 spheres or 128 boxes and checks its invariants.  out = {nodes, objects in the tree, depth, most slots
  * used by a node (<= 4), objects or nodes not reached exactly once, objects not inside their slot's box,

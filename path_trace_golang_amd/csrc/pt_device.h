@@ -144,6 +144,8 @@ struct DevFrame {
     float origin_bound;  // rays whose origin leaves [-origin_bound, origin_bound]^3 keep every candidate
     float pad_f;
     double scene_bound;  // Bs: every finite object (inflated) lies inside [-Bs, Bs]^3
+    double clip_bound;   // 3.5 B: rays that start inside [-clip_bound, clip_bound]^3 are scanned from their origin, the others
+                         // are clipped against the scene cube first (the FP32 bounds were analysed for origins within 4 B)
     double margin;       // m = B/4096: inflation of every FP32 bound
     uint64_t seed_key;   // ptm::seed_key(seed)
     double inv_width;    // 1/(W-1)  renderer.go:95
@@ -162,7 +164,8 @@ struct PathQueue {
     unsigned long long *rs;     // [cap] stream state
     uint32_t *job;              // [cap]
     int32_t *depth;             // [cap] remaining depth (renderer.go:286 counts down)
-    int32_t *best;              // [cap] glass queue: object hit
+    int32_t *best;              // [cap] glass queue: object hit; exit queue of the wavefront form: the glass material
+    int32_t *hit;               // [cap] wavefront form: answer of the traversal pass (object index or -1; its t goes to plane 9 of d)
     uint32_t *jseg, *jdraw;     // [cap] per-job counters so far (PT_FLAG_PIXEL_STATS) or null
     uint32_t *count;            // entries appended so far
     uint32_t cap;

@@ -131,6 +131,38 @@ struct RayD {
     double ox, oy, oz, dx, dy, dz;
 };
 
+// IEEE division n / d with the reciprocal work shared between several numerators.  The compiler's f64 division is
+//   ds = div_scale(d), ns = div_scale(n); y = rcp(ds) refined by two Newton steps; q0 = ns*y; r = fma(-ds, q0, ns);
+//   q = div_fmas(r, y, q0); div_fixup(q, d, n)
+// where div_scale / div_fmas / div_fixup only act on operands near the ends of the exponent range, zeros, infinities
+// and NaNs (CDNA ISA, V_DIV_SCALE_F64: exponent difference >= 768, denormal operand, reciprocal or quotient, numerator
+// below 2^-970).  Away from those the quotient is exactly fma(fma(-d, n*y, n), y, n*y) with a y that depends on d alone --
+// computed once per denominator here (v_rcp_f64 is 16 cycles, each fma 4).  The guard: with the denominator within
+// 2^+-340 (the callers' `tame` rays, or a roulette probability) and the numerator within 2^+-300, none of the special
+// cases can arise; a zero numerator and anything else are treated apart.  Checked bit for bit against `/`
+// on 4*10^9 random and patterned operand pairs by pt_debug_div_selftest (tests/test_div_shared_gpu.py).
+__device__ __forceinline__ double div_recip(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    return y;
+}
+__device__ __forceinline__ double div_shared(double n, double d, double y) {
+    const double q = n * y;
+    const double r = __builtin_fma(-d, q, n);
+    double f = __builtin_fma(r, y, q);
+    const uint32_t ex = ((uint32_t)(ptm::to_bits(n) >> 52)) & 0x7ffu;
+    if (!(ex - (1023u - 300u) <= 600u)) {  // numerator outside 2^+-300: rare
+        // a zero keeps the sign the product n*y gave it (the residual step would turn -0 / d into +0); everything
+        // else out here (huge, tiny, denormal, infinite, NaN) takes the plain division
+        if (n == 0) f = q;
+        else f = n / d;
+    }
+    return f;
+}
+
 // Exact sphere test, objects.go:37-61: first root (near, then far) that lies in [tmin, tmax].
 __device__ __forceinline__ bool sphere_exact(double cx, double cy, double cz, double radius_sq, const RayD &r, double a,
                                              double tmin, double tmax, double &t) {
@@ -153,11 +185,54 @@ __device__ __forceinline__ bool sphere_exact(double cx, double cy, double cz, do
     return valid;
 }
 
+// The same with the two divisions by a = |d|^2 sharing ya = div_recip(a) (a within 2^+-340: the caller's `tame` test).
+__device__ __forceinline__ bool sphere_exact_shared(double cx, double cy, double cz, double radius_sq, const RayD &r, double a, double ya,
+                                                    double tmin, double tmax, double &t) {
+    const double ocx = r.ox - cx, ocy = r.oy - cy, ocz = r.oz - cz;
+    const double halfB = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+    const double ocLenSq = ocx * ocx + ocy * ocy + ocz * ocz;
+    const double c = ocLenSq - radius_sq;
+    const double disc = halfB * halfB - a * c;
+    bool valid = false;
+    if (!(disc < 0)) {
+        const double sq = ptm::f_sqrt(disc);
+        double root = div_shared(-halfB - sq, a, ya);
+        valid = true;
+        if (root < tmin || root > tmax) {
+            root = div_shared(-halfB + sq, a, ya);
+            if (root < tmin || root > tmax) valid = false;
+        }
+        t = root;
+    }
+    return valid;
+}
+
 // Exact slab test, objects.go:141-179.  t0 only grows and t1 only shrinks, so the per-axis early
 // return of objects.go:176 equals the single test after the third axis.
+// MINMAX: the updates as v_max_f64 / v_min_f64 (one 4-cycle instruction instead of a compare and two selects).  Equal to
+// the compares whenever t0 and t1 start as numbers: a NaN slab parameter (0 * inf) is skipped by both forms, and a zero
+// of either sign can only ever sit in t1, where only `t1 <= t0` with t0 >= tmin > 0 looks at it.  The plain scan keeps the
+// compare form: there tmax can be the NaN root of a degenerate sphere, which `if (tf < t1)` leaves in place.
+template <bool MINMAX = false>
 __device__ __forceinline__ bool box_exact(double ax, double ay, double az, double bx, double by, double bz, const RayD &r,
                                           double ivx, double ivy, double ivz, double tmin, double tmax, double &t) {
     double t0 = tmin, t1 = tmax;
+    if (MINMAX) {
+        double tn = (ax - r.ox) * ivx, tf = (bx - r.ox) * ivx;
+        if (ivx < 0) { const double s = tn; tn = tf; tf = s; }
+        t0 = __builtin_fmax(t0, tn);
+        t1 = __builtin_fmin(t1, tf);
+        tn = (ay - r.oy) * ivy; tf = (by - r.oy) * ivy;
+        if (ivy < 0) { const double s = tn; tn = tf; tf = s; }
+        t0 = __builtin_fmax(t0, tn);
+        t1 = __builtin_fmin(t1, tf);
+        tn = (az - r.oz) * ivz; tf = (bz - r.oz) * ivz;
+        if (ivz < 0) { const double s = tn; tn = tf; tf = s; }
+        t0 = __builtin_fmax(t0, tn);
+        t1 = __builtin_fmin(t1, tf);
+        t = t0;
+        return !(t1 <= t0);
+    }
     double tn = (ax - r.ox) * ivx, tf = (bx - r.ox) * ivx;
     if (ivx < 0) { const double s = tn; tn = tf; tf = s; }
     if (tn > t0) t0 = tn;
@@ -231,7 +306,8 @@ __device__ __forceinline__ void scan_uniform(const DevFrame &F, ObjPtr g_obj, co
 
 
 // A ray against the cube [-Bs, Bs]^3 that holds every finite object, in FP64.
-//   inside   : the origin is in the cube (ts = 0, nothing else to do)
+//   inside   : the origin is within 3.5 scene sizes (F.clip_bound): ts = 0, nothing else to do -- the FP32 tests are
+//              conservative from any origin within 4 B, and most rays start inside the scene
 //   miss     : the ray never is inside the cube at a parameter >= tmin  -> no sphere or box can be hit
 //   te, ts   : entry parameter; the FP32 tests run from the entry point o + d*ts (parameters relative to ts)
 //   far      : the origin is so far out (more than ~2000 scene sizes) that the REFERENCE's own FP64 sphere
@@ -249,7 +325,8 @@ struct Clip {
 __device__ __forceinline__ Clip clip_ray(const DevFrame &F, const RayD &r, double tmin) {
     Clip c{0.0, 0.0, 0.0, false, false};
     double Bs = F.scene_bound;
-    if (!(ptm::f_abs(r.ox) <= Bs && ptm::f_abs(r.oy) <= Bs && ptm::f_abs(r.oz) <= Bs)) {
+    const double Cb = F.clip_bound;
+    if (!(ptm::f_abs(r.ox) <= Cb && ptm::f_abs(r.oy) <= Cb && ptm::f_abs(r.oz) <= Cb)) {
         // v_rcp_f64 (relative error < 2^-26) instead of three IEEE divisions: the entry point may be off by
         // ~1.5e-8 * reach <= 3e-5 B, and the cube keeps B/512 - m = 1.7e-3 B of clearance around every bound
         const double ix = __builtin_amdgcn_rcp(r.dx), iy = __builtin_amdgcn_rcp(r.dy), iz = __builtin_amdgcn_rcp(r.dz);
@@ -404,6 +481,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
 
     // ---- narrow phase: spheres, then boxes, each lane on its own candidates (index order)
     uint32_t ms = cs;
+    const double ya = div_recip(a);  // both roots of every sphere divide by a
     while (__ballot(ms != 0) != 0) {
         if (ms != 0) {
             PH_BEGIN(SEC_NSPH)
@@ -411,7 +489,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
             ms &= ms - 1;
             const DevObj &o = s_obj[i];
             double t = 0;
-            bool acc = sphere_exact(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, tmin, tmax, t) &&
+            bool acc = sphere_exact_shared(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, ya, tmin, tmax, t) &&
                        wins(mode, false, i, t, best, best_is_box, tmax);
             if (MODE != 0 && acc && mode != 0) acc = exit_candidate_ok(o, KIND_SPHERE, r, t);
             // selects, not branches: the update is four v_cndmask
@@ -432,7 +510,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
                 const DevObj &o = s_obj[i];
                 double t = 0;
                 // the range is left open at the top here: `wins` compares t with tmax (strictly for a box)
-                bool acc = box_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t) &&
+                bool acc = box_exact<true>(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t) &&
                            wins(mode, true, i, t, best, best_is_box, tmax);
                 if (MODE != 0 && acc && mode != 0) acc = exit_candidate_ok(o, KIND_BOX, r, t);
                 best = acc ? i : best;
@@ -457,6 +535,7 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
     best = -1;
     bool best_is_box = false;
     const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+    const double ya = div_recip(a);
 
     PH_BEGIN(SEC_PLANE)
     for (int k = 0; k < F.n_plane; k++) {
@@ -518,7 +597,7 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
                 cs &= cs - 1;
                 const DevObj &o = s_obj[i];
                 double t = 0;
-                bool acc = sphere_exact(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, tmin, tmax, t) &&
+                bool acc = sphere_exact_shared(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, ya, tmin, tmax, t) &&
                            wins(mode, false, i, t, best, best_is_box, tmax);
                 if (acc && mode != 0) acc = exit_candidate_ok(o, KIND_SPHERE, r, t);
                 best = acc ? i : best;
@@ -553,7 +632,7 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
                     cb &= cb - 1;
                     const DevObj &o = s_obj[i];
                     double t = 0;
-                    bool acc = box_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t) &&
+                    bool acc = box_exact<true>(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t) &&
                                wins(mode, true, i, t, best, best_is_box, tmax);
                     if (acc && mode != 0) acc = exit_candidate_ok(o, KIND_BOX, r, t);
                     best = acc ? i : best;
@@ -607,6 +686,7 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     best = resume ? S.best : -1;
     bool best_is_box = resume ? S.best_is_box : false;
     const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+    const double ya = div_recip(a);
 
     if (!resume) {
     PH_BEGIN(SEC_PLANE)
@@ -761,10 +841,10 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 bool valid;
                 const bool is_box = kind == KIND_BOX;
                 if (is_box)
-                    valid = box_exact(bo.o.a[0], bo.o.a[1], bo.o.a[2], bo.o.b[0], bo.o.b[1], bo.o.b[2], r, ivx, ivy, ivz, tmin,
+                    valid = box_exact<true>(bo.o.a[0], bo.o.a[1], bo.o.a[2], bo.o.b[0], bo.o.b[1], bo.o.b[2], r, ivx, ivy, ivz, tmin,
                                       ptm::max_float64(), t);
                 else
-                    valid = sphere_exact(bo.o.a[0], bo.o.a[1], bo.o.a[2], bo.o.radius_sq, r, a, tmin, tmax, t);
+                    valid = sphere_exact_shared(bo.o.a[0], bo.o.a[1], bo.o.a[2], bo.o.radius_sq, r, a, ya, tmin, tmax, t);
                 if (valid && wins(mode, is_box, i, t, best, best_is_box, tmax) &&
                     (mode == 0 || exit_candidate_ok(bo.o, kind, r, t))) {
                     best = i;
@@ -967,8 +1047,11 @@ __device__ __forceinline__ bool roulette_advance(int &depth, double attx, double
             const double xi = draw_next<STATS>(rs, c_draw, j_draw);
             if (xi > rrProb) {
                 finished = true;
-            } else {
-                attx /= rrProb; atty /= rrProb; attz /= rrProb;
+            } else {  // three divisions by the same probability (1e-6 <= rrProb <= 0.95)
+                const double yp = div_recip(rrProb);
+                attx = div_shared(attx, rrProb, yp);
+                atty = div_shared(atty, rrProb, yp);
+                attz = div_shared(attz, rrProb, yp);
             }
         }
     }
@@ -978,6 +1061,135 @@ __device__ __forceinline__ bool roulette_advance(int &depth, double attx, double
         if (depth <= 0) finished = true;  // renderer.go:287-289 contributes zero
     }
     return finished;
+}
+
+// What the surface does with the path at its closest hit (renderer.go:308-319): the hit record of the winner
+// (objects.go:63-88, :114-132, :181-221), `emitted` and material.scatter (materials.go:67-224).
+//   finished     the path ends here with radiance `term` (an emissive surface: its emission; a failed scatter: 0)
+//   exit_search  (GLASS only) a dielectric front face: the way out must be found before roulette (renderer.go:316-319),
+//                exit_mat = the material
+//   otherwise    o, d hold the scattered ray, att its attenuation: Russian roulette comes next
+// GLASS = false: the caller never passes a dielectric hit (split passes park those for glass_kernel).
+template <bool STATS, bool GLASS>
+__device__ __forceinline__ void shade_hit(const DevObj &o, const DevMat *s_mat, double tmax, double &ox, double &oy, double &oz, double &dx,
+                                          double &dy, double &dz, uint64_t &rs, uint32_t &c_draw, uint32_t &j_draw, bool &finished,
+                                          double &termx, double &termy, double &termz, double &attx, double &atty, double &attz,
+                                          bool &exit_search, int &exit_mat) {
+            const int kind = o.kind & 0xff;
+        const double px = ox + dx * tmax, py = oy + dy * tmax, pz = oz + dz * tmax;
+        double nx, ny, nz;
+        outward_normal(o, kind, px, py, pz, nx, ny, nz);
+        const bool ff = (dx * nx + dy * ny + dz * nz) < 0;
+        if (!ff) { nx = -nx; ny = -ny; nz = -nz; }
+        const int mi = o.mat;
+        const DevMat &m = s_mat[mi];
+        const int typ = m.typ;
+        if (typ == MAT_EMISSIVE) {  // materials.go:67-72, :202-203
+            finished = true;
+            termx = m.emit[0]; termy = m.emit[1]; termz = m.emit[2];
+        } else {
+            // unit direction for the specular kinds (materials.go:102-109, :175-182, :207-214)
+            double ux = 0, uy = 0, uz = 0, rfx = 0, rfy = 0, rfz = 0;
+            bool zero_dir = false;
+            if (typ != MAT_LAMBERT) {
+                const double dirLen = ptm::f_sqrt(dx * dx + dy * dy + dz * dz);
+                if (dirLen == 0) {
+                    zero_dir = true;
+                } else {
+                    const double invLen = 1.0 / dirLen;
+                    ux = dx * invLen; uy = dy * invLen; uz = dz * invLen;
+                    reflect_vec(ux, uy, uz, nx, ny, nz, rfx, rfy, rfz);
+                }
+            }
+            if (zero_dir) {
+                finished = true;  // scatter fails -> emitted (0)
+            } else {
+                double ndx = rfx, ndy = rfy, ndz = rfz;  // mirror / smooth metal / reflecting glass
+                const bool cosine = (typ == MAT_LAMBERT) || (typ == MAT_METAL && m.rough > 1e-6);
+                if (cosine) {
+                    // randomCosineDirection, math.go:94-131, about the normal (lambert)
+                    // or about the mirror direction (rough metal, materials.go:119)
+                    const double wx = (typ == MAT_LAMBERT) ? nx : rfx;
+                    const double wy = (typ == MAT_LAMBERT) ? ny : rfy;
+                    const double wz = (typ == MAT_LAMBERT) ? nz : rfz;
+                    const double r1 = draw_next<STATS>(rs, c_draw, j_draw);
+                    const double r2 = draw_next<STATS>(rs, c_draw, j_draw);
+                    const double phi = 6.283185307179586 * r1;
+                    const double cosTheta = ptm::f_sqrt(r2);
+                    const double sinTheta = ptm::f_sqrt(1.0 - r2);
+                    const bool xmajor = ptm::f_abs(wx) > 0.9;
+                    const double hx = xmajor ? 0.0 : 1.0, hy = xmajor ? 1.0 : 0.0, hz = 0.0;
+                    // vVec = unit(w x h), uVec = vVec x w
+                    double cx = wy * hz - wz * hy;
+                    double cy = wz * hx - wx * hz;
+                    double cz = wx * hy - wy * hx;
+                    const double cl = ptm::f_sqrt(cx * cx + cy * cy + cz * cz);
+                    if (cl != 0) {
+                        const double inv = 1.0 / cl;
+                        cx = cx * inv; cy = cy * inv; cz = cz * inv;
+                    }
+                    const double bx = cy * wz - cz * wy;
+                    const double by = cz * wx - cx * wz;
+                    const double bz = cx * wy - cy * wx;
+                    double sn, cs;
+                    ptm::sincos_pos(phi, &sn, &cs);
+                    const double lx = sinTheta * cs, ly = sinTheta * sn, lz = cosTheta;
+                    double sx = lx * bx + ly * cx + lz * wx;
+                    double sy = lx * by + ly * cy + lz * wy;
+                    double sz = lx * bz + ly * cz + lz * wz;
+                    if (typ == MAT_LAMBERT) {
+                        if (m.rough > 1e-6) {  // materials.go:84-91
+                            double qx, qy, qz;
+                            for (;;) {
+                                const double d0 = draw_next<STATS>(rs, c_draw, j_draw);
+                                const double d1 = draw_next<STATS>(rs, c_draw, j_draw);
+                                const double d2 = draw_next<STATS>(rs, c_draw, j_draw);
+                                qx = d0 * 2 - 1; qy = d1 * 2 - 1; qz = d2 * 2 - 1;
+                                if (qx * qx + qy * qy + qz * qz >= 1.0) continue;
+                                break;
+                            }
+                            sx += qx * m.rough * 0.1;
+                            sy += qy * m.rough * 0.1;
+                            sz += qz * m.rough * 0.1;
+                            const double l = ptm::f_sqrt(sx * sx + sy * sy + sz * sz);
+                            if (l != 0) {
+                                const double inv = 1.0 / l;
+                                sx = sx * inv; sy = sy * inv; sz = sz * inv;
+                            }
+                        }
+                        ndx = sx; ndy = sy; ndz = sz;
+                    } else {
+                        // materials.go:121-148
+                        const double alpha = m.rough_sq;
+                        double mx = rfx * (1.0 - alpha) + sx * alpha;
+                        double my = rfy * (1.0 - alpha) + sy * alpha;
+                        double mz = rfz * (1.0 - alpha) + sz * alpha;
+                        const double lenSq = mx * mx + my * my + mz * mz;
+                        if (lenSq < 1e-8) {
+                            mx = rfx; my = rfy; mz = rfz;
+                        } else {
+                            const double inv = 1.0 / ptm::f_sqrt(lenSq);
+                            mx *= inv; my *= inv; mz *= inv;
+                        }
+                        const double dot = mx * nx + my * ny + mz * nz;
+                        if (dot <= 0) { mx = rfx; my = rfy; mz = rfz; }
+                        ndx = mx; ndy = my; ndz = mz;
+                    }
+                }
+                if (GLASS && typ == MAT_DIELECTRIC) {  // materials.go:162-200
+                    dielectric_scatter<STATS>(m, ff, ux, uy, uz, nx, ny, nz, rfx, rfy, rfz, rs, c_draw, j_draw, ndx, ndy, ndz);
+                } else {
+                    attx = m.albedo[0]; atty = m.albedo[1]; attz = m.albedo[2];
+                }
+                // scattered ray starts at the hit point (no offset)
+                ox = px; oy = py; oz = pz;
+                dx = ndx; dy = ndy; dz = ndz;
+                if (GLASS && typ == MAT_DIELECTRIC && ff) {
+                    exit_search = true;  // renderer.go:316-319: find the way out before roulette
+                    exit_mat = mi;
+                }
+            }
+        }
 }
 
 // Hides where a (wave-uniform) pointer came from, so that what is read through it is re-read at the point of use
@@ -1300,132 +1512,16 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const TraceArgs A) {
                     to_glass = true;  // dielectric: shaded by glass_kernel
                 } else {
                     SEC_BEGIN(SEC_HITREC)
-                    const DevObj &o = s_obj[best];
-                    const int kind = o.kind & 0xff;
-                    const double px = ox + dx * tmax, py = oy + dy * tmax, pz = oz + dz * tmax;
-                    double nx, ny, nz;
-                    outward_normal(o, kind, px, py, pz, nx, ny, nz);
-                    const bool ff = (dx * nx + dy * ny + dz * nz) < 0;
-                    if (!ff) { nx = -nx; ny = -ny; nz = -nz; }
-                    const int mi = o.mat;
-                    const DevMat &m = s_mat[mi];
-                    const int typ = m.typ;
-                    SEC_END(SEC_HITREC)
-                    if (typ == MAT_EMISSIVE) {  // materials.go:67-72, :202-203
-                        finished = true;
-                        termx = m.emit[0]; termy = m.emit[1]; termz = m.emit[2];
-                    } else {
-                        // unit direction for the specular kinds (materials.go:102-109, :175-182, :207-214)
-                        double ux = 0, uy = 0, uz = 0, rfx = 0, rfy = 0, rfz = 0;
-                        bool zero_dir = false;
-                        if (typ != MAT_LAMBERT) {
-                            SEC_BEGIN(SEC_UNITDIR)
-                            const double dirLen = ptm::f_sqrt(dx * dx + dy * dy + dz * dz);
-                            if (dirLen == 0) {
-                                zero_dir = true;
-                            } else {
-                                const double invLen = 1.0 / dirLen;
-                                ux = dx * invLen; uy = dy * invLen; uz = dz * invLen;
-                                reflect_vec(ux, uy, uz, nx, ny, nz, rfx, rfy, rfz);
-                            }
-                            SEC_END(SEC_UNITDIR)
-                        }
-                        if (zero_dir) {
-                            finished = true;  // scatter fails -> emitted (0)
-                        } else {
-                            double ndx = rfx, ndy = rfy, ndz = rfz;  // mirror / smooth metal / reflecting glass
-                            const bool cosine = (typ == MAT_LAMBERT) || (typ == MAT_METAL && m.rough > 1e-6);
-                            if (cosine) {
-                                SEC_BEGIN(SEC_COSINE)
-                                // randomCosineDirection, math.go:94-131, about the normal (lambert)
-                                // or about the mirror direction (rough metal, materials.go:119)
-                                const double wx = (typ == MAT_LAMBERT) ? nx : rfx;
-                                const double wy = (typ == MAT_LAMBERT) ? ny : rfy;
-                                const double wz = (typ == MAT_LAMBERT) ? nz : rfz;
-                                PT_DRAW(r1)
-                                PT_DRAW(r2)
-                                const double phi = 6.283185307179586 * r1;
-                                const double cosTheta = ptm::f_sqrt(r2);
-                                const double sinTheta = ptm::f_sqrt(1.0 - r2);
-                                const bool xmajor = ptm::f_abs(wx) > 0.9;
-                                const double hx = xmajor ? 0.0 : 1.0, hy = xmajor ? 1.0 : 0.0, hz = 0.0;
-                                // vVec = unit(w x h), uVec = vVec x w
-                                double cx = wy * hz - wz * hy;
-                                double cy = wz * hx - wx * hz;
-                                double cz = wx * hy - wy * hx;
-                                const double cl = ptm::f_sqrt(cx * cx + cy * cy + cz * cz);
-                                if (cl != 0) {
-                                    const double inv = 1.0 / cl;
-                                    cx = cx * inv; cy = cy * inv; cz = cz * inv;
-                                }
-                                const double bx = cy * wz - cz * wy;
-                                const double by = cz * wx - cx * wz;
-                                const double bz = cx * wy - cy * wx;
-                                double sn, cs;
-                                ptm::sincos_pos(phi, &sn, &cs);
-                                const double lx = sinTheta * cs, ly = sinTheta * sn, lz = cosTheta;
-                                double sx = lx * bx + ly * cx + lz * wx;
-                                double sy = lx * by + ly * cy + lz * wy;
-                                double sz = lx * bz + ly * cz + lz * wz;
-                                if (typ == MAT_LAMBERT) {
-                                    if (m.rough > 1e-6) {  // materials.go:84-91
-                                        double qx, qy, qz;
-                                        for (;;) {
-                                            PT_DRAW(d0)
-                                            PT_DRAW(d1)
-                                            PT_DRAW(d2)
-                                            qx = d0 * 2 - 1; qy = d1 * 2 - 1; qz = d2 * 2 - 1;
-                                            if (qx * qx + qy * qy + qz * qz >= 1.0) continue;
-                                            break;
-                                        }
-                                        sx += qx * m.rough * 0.1;
-                                        sy += qy * m.rough * 0.1;
-                                        sz += qz * m.rough * 0.1;
-                                        const double l = ptm::f_sqrt(sx * sx + sy * sy + sz * sz);
-                                        if (l != 0) {
-                                            const double inv = 1.0 / l;
-                                            sx = sx * inv; sy = sy * inv; sz = sz * inv;
-                                        }
-                                    }
-                                    ndx = sx; ndy = sy; ndz = sz;
-                                } else {
-                                    // materials.go:121-148
-                                    const double alpha = m.rough_sq;
-                                    double mx = rfx * (1.0 - alpha) + sx * alpha;
-                                    double my = rfy * (1.0 - alpha) + sy * alpha;
-                                    double mz = rfz * (1.0 - alpha) + sz * alpha;
-                                    const double lenSq = mx * mx + my * my + mz * mz;
-                                    if (lenSq < 1e-8) {
-                                        mx = rfx; my = rfy; mz = rfz;
-                                    } else {
-                                        const double inv = 1.0 / ptm::f_sqrt(lenSq);
-                                        mx *= inv; my *= inv; mz *= inv;
-                                    }
-                                    const double dot = mx * nx + my * ny + mz * nz;
-                                    if (dot <= 0) { mx = rfx; my = rfy; mz = rfz; }
-                                    ndx = mx; ndy = my; ndz = mz;
-                                }
-                                SEC_END(SEC_COSINE)
-                            }
-                            if (!SPLIT && typ == MAT_DIELECTRIC) {  // materials.go:162-200
-                                SEC_BEGIN(SEC_DIEL)
-                                dielectric_scatter<STATS>(m, ff, ux, uy, uz, nx, ny, nz, rfx, rfy, rfz, rs, c_draw, j_draw, ndx, ndy, ndz);
-                                SEC_END(SEC_DIEL)
-                            } else {
-                                attx = m.albedo[0]; atty = m.albedo[1]; attz = m.albedo[2];
-                            }
-                            // scattered ray starts at the hit point (no offset)
-                            ox = px; oy = py; oz = pz;
-                            dx = ndx; dy = ndy; dz = ndz;
-                            if (!SPLIT && typ == MAT_DIELECTRIC && ff) {
-                                mode = 1;  // renderer.go:316-319: find the way out before roulette
-                                exit_mat = mi;
-                                c_exit++;
-                            } else {
-                                do_rr = true;
-                            }
-                        }
+                    bool exit_search = false;
+                    shade_hit<STATS, !SPLIT>(s_obj[best], s_mat, tmax, ox, oy, oz, dx, dy, dz, rs, c_draw, j_draw, finished, termx, termy,
+                                             termz, attx, atty, attz, exit_search, exit_mat);
+                    if (exit_search) {
+                        mode = 1;
+                        c_exit++;
+                    } else if (!finished) {
+                        do_rr = true;
                     }
+                    SEC_END(SEC_HITREC)
                 }
             } else {
                 // exit search done (renderer.go:352-370); the hit point of the entry is the ray origin
@@ -1845,6 +1941,36 @@ __global__ __launch_bounds__(PT_BLOCK) void untile_kernel(const UntileArgs U) {
     }
     if (U.u32a) U.u32a[o] = U.tiles_u32a[pix];
     if (U.u32b) U.u32b[o] = U.tiles_u32b[pix];
+}
+
+// Self-test of div_shared against the compiler's IEEE division: `per_thread` operand pairs per thread, exponents drawn
+// over the guarded ranges (denominator 2^+-340, numerator 2^+-300, every 16th numerator outside them or zero to take
+// the fall-back), mantissas random or at their extremes.  out[0] += pairs whose bits differ.
+__global__ __launch_bounds__(PT_BLOCK) void div_selftest_kernel(unsigned long long seed, uint32_t per_thread, unsigned long long *out) {
+    uint64_t s = ptm::mix64(seed + (uint64_t)(blockIdx.x * PT_BLOCK + threadIdx.x) * PTM_GOLDEN);
+    uint32_t bad = 0;
+    for (uint32_t k = 0; k < per_thread; k++) {
+        s += PTM_GOLDEN;
+        const uint64_t h0 = ptm::mix64(s), h1 = ptm::mix64(s ^ 0x5851f42d4c957f2dULL), h2 = ptm::mix64(s + 0x14057b7ef767814fULL);
+        const uint32_t sel = (uint32_t)(h2 >> 40) & 15u;
+        uint64_t md = h0 & 0xfffffffffffffULL, mn = h1 & 0xfffffffffffffULL;
+        if (((h2 >> 8) & 7u) == 0) md = 0;
+        if (((h2 >> 11) & 7u) == 0) md = 0xfffffffffffffULL;
+        if (((h2 >> 14) & 7u) == 0) mn = 0;
+        if (((h2 >> 17) & 7u) == 0) mn = 0xfffffffffffffULL;
+        const uint64_t ed = 1023u - 340u + (uint32_t)((h2 >> 20) % 681u);
+        uint64_t en = 1023u - 300u + (uint32_t)((h2 >> 44) % 601u);
+        if (sel == 0) en = (h1 >> 52) & 0x7ffu;  // anything, also denormals, infinities and NaNs: the guard must send them to `/`
+        const double d = ptm::from_bits(((h0 >> 63) << 63) | (ed << 52) | md);
+        double n = ptm::from_bits(((h1 >> 63) << 63) | (en << 52) | mn);
+        if (sel == 1) n = (h1 >> 63) ? -0.0 : 0.0;
+        const double q0 = n / d;
+        const double q1 = div_shared(n, d, div_recip(d));
+        const bool same = ptm::to_bits(q0) == ptm::to_bits(q1) || (q0 != q0 && q1 != q1);
+        bad += same ? 0u : 1u;
+    }
+    const uint32_t w = wave_sum(bad);
+    if ((threadIdx.x & (PT_WAVE - 1)) == 0 && w) atomicAdd(out, (unsigned long long)w);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@
 #include "pt_bvh.h"
 #include "pt_device.h"
 #include "pt_kernels.h"
+#include "pt_wavefront.h"
 #include "pt_math.h"
 
 using namespace ptd;
@@ -101,7 +102,12 @@ struct Device {
     // path-state queues of the split passes (one entry per job of a chunk at most)
     DevBuf<double> gq_d, cq_d;
     DevBuf<unsigned long long> gq_rs, cq_rs;
-    DevBuf<uint32_t> gq_u32, cq_u32;  // job, depth, best, jseg, jdraw planes
+    DevBuf<uint32_t> gq_u32, cq_u32;  // job, depth, best, hit, jseg, jdraw planes
+    DevBuf<double> xq_d;              // third queue of the wavefront form (gq = exit queue, cq / xq = the two path queues)
+    DevBuf<unsigned long long> xq_rs;
+    DevBuf<uint32_t> xq_u32;
+    int blocks_per_cu_wf = 0;
+    DevBuf<uint32_t> wf_perm, wf_key, wf_bins;  // ray sorting of the wavefront form
     size_t q_cap = 0;
     DevBuf<unsigned long long> counters;
     DevBuf<unsigned long long> prof;
@@ -132,6 +138,8 @@ struct Frame {
     bool stats_on = false;
     size_t lds_bytes = 0;
     size_t glass_lds_bytes = 0;
+    bool wavefront = false;  // the wavefront form (pt_wavefront.h) instead of the all-in-one loop
+    size_t shade_lds_bytes = 0;
     int split_rounds = 0;  // trace + glass pass pairs before the all-in-one pass (0: all-in-one only)
     bool has_glass = false;  // some object is dielectric
     int scan = 0;  // ptk::SCAN_* used for this frame
@@ -176,6 +184,9 @@ struct pt_ctx {
     DevBuf<double> f_accum;
     DevBuf<uint32_t> f_seg, f_draw;
     size_t l_budget_bytes = (size_t)48 << 30;  // per-chunk job buffers (radiance, primary rays, path-state queues): a sixth of the 288 GB
+    int pipeline = -1;     // PTCORE_PIPELINE=mega|wavefront: -1 = by scene (wavefront for BVH scenes)
+    int wf_min_lanes = 40; // PTCORE_WF_MIN_LANES: the walk loop of a traversal pass is left for a refill below this many walking lanes
+    int wf_sort = 0;       // PTCORE_WF_SORT=1: reorder the paths of a level by direction octant and origin cell
     int split_rounds = 2;  // PTCORE_SPLIT_ROUNDS: trace + glass pass pairs per chunk before the all-in-one pass (bitmask scan only)
     uint32_t claim = 256;
     int max_blocks_per_cu = 8;
@@ -423,6 +434,7 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     F.box_all = fr.bbox.size() >= 32 ? 0xffffffffu : ((1u << fr.bbox.size()) - 1u);
     F.origin_bound = (float)std::min(4.0 * B, 3.0e38);
     F.scene_bound = B * (1.0 + 1.0 / 512.0);  // the inflation is B/4096
+    F.clip_bound = B * 3.5;
     F.margin = m;
 }
 
@@ -558,16 +570,26 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         if (e == hipSuccess) e = d.ray_ndraw.reserve(njobs_max);
         if (e == hipSuccess && fr.stats_on) e = d.job_seg.reserve(njobs_max);
         if (e == hipSuccess && fr.stats_on) e = d.job_draw.reserve(njobs_max);
-        if (fr.split_rounds > 0 && fr.has_glass) {  // path-state queues: 10 doubles + stream state + job, depth, hit object (+ 2 counters) per entry, twice
+        if (fr.wavefront || (fr.split_rounds > 0 && fr.has_glass)) {  // path-state queues: 10 doubles + stream state + job, depth, hit object (+ 2 counters) per entry, twice
             // one entry per job at most, plus the slots the waves of a trace pass reserve in blocks and may leave empty
             const size_t qcap = njobs_max + (size_t)d.num_cu * 32u * PT_CONT_BLOCK;
-            const size_t planes = fr.stats_on ? 5 : 3;
+            const size_t planes = fr.stats_on ? 6 : 4;
             if (e == hipSuccess) e = d.gq_d.reserve(10 * qcap);
             if (e == hipSuccess) e = d.cq_d.reserve(10 * qcap);
             if (e == hipSuccess) e = d.gq_rs.reserve(qcap);
             if (e == hipSuccess) e = d.cq_rs.reserve(qcap);
             if (e == hipSuccess) e = d.gq_u32.reserve(planes * qcap);
             if (e == hipSuccess) e = d.cq_u32.reserve(planes * qcap);
+            if (fr.wavefront) {
+                if (e == hipSuccess) e = d.xq_d.reserve(10 * qcap);
+                if (e == hipSuccess) e = d.xq_rs.reserve(qcap);
+                if (e == hipSuccess) e = d.xq_u32.reserve(planes * qcap);
+                if (ctx->wf_sort) {
+                    if (e == hipSuccess) e = d.wf_perm.reserve(qcap);
+                    if (e == hipSuccess) e = d.wf_key.reserve(qcap);
+                    if (e == hipSuccess) e = d.wf_bins.reserve(PT_WF_BINS + 8);
+                }
+            }
             d.q_cap = qcap;
         }
         if (e == hipSuccess) break;
@@ -575,6 +597,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         if (e != hipErrorOutOfMemory || fr.chunk <= 1) return fail(PT_ERR_HIP, std::string("job buffers: ") + hipGetErrorString(e));
         d.L.release(); d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release(); d.job_seg.release(); d.job_draw.release();
         d.gq_d.release(); d.cq_d.release(); d.gq_rs.release(); d.cq_rs.release(); d.gq_u32.release(); d.cq_u32.release();
+        d.xq_d.release(); d.xq_rs.release(); d.xq_u32.release();
         fr.chunk = std::max<uint32_t>(1, fr.chunk / 2);
         if (std::getenv("PTCORE_VERBOSE")) std::fprintf(stderr, "ptcore: device %d is short of memory, samples per pass reduced to %u\n", d.ordinal, fr.chunk);
     }
@@ -589,11 +612,150 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
     d.blocks_per_cu = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
     d.blocks_per_cu_split = d.blocks_per_cu;
     d.blocks_per_cu_glass = 1;
+    if (fr.wavefront) {
+        const bool bvh = fr.scan == ptk::SCAN_BVH || fr.scan == ptk::SCAN_VERIFY_BVH;
+        if (bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::wf_traverse_kernel<0, false>, PT_BLOCK, lds));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::wf_scan_flat_kernel<0, false>, PT_BLOCK, lds));
+        d.blocks_per_cu_wf = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
+    }
     if (fr.split_rounds > 0) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, true), PT_BLOCK, lds));
         d.blocks_per_cu_split = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_glass(fr.stats_on, fr.scan), PT_BLOCK, fr.glass_lds_bytes));
         d.blocks_per_cu_glass = std::max(1, std::min(nb, 8));
+    }
+    return PT_OK;
+}
+
+// One chunk in the wavefront form (pt_wavefront.h): primary rays are in the ray buffers (raygen_kernel ran); queue words:
+// [0] item cursor of the running traversal pass, [1] [2] entries of the two path queues, [3] entries of the exit queue.
+int32_t dev_step_wavefront(pt_ctx *ctx, Device &d, const DevFrame &F, const TraceBuffers &B) {
+    Frame &fr = ctx->frame;
+    const bool bvh = fr.scan == ptk::SCAN_BVH || fr.scan == ptk::SCAN_VERIFY_BVH;
+    const bool verify = fr.scan == ptk::SCAN_VERIFY_BVH || fr.scan == ptk::SCAN_VERIFY;
+    const bool stats = fr.stats_on;
+    unsigned int *qw = d.queue.p;
+    const size_t cap = d.q_cap;
+    auto bind = [&](PathQueue &q, DevBuf<double> &qd, DevBuf<unsigned long long> &qrs, DevBuf<uint32_t> &qu, unsigned int *count) {
+        std::memset(&q, 0, sizeof q);
+        q.d = qd.p;
+        q.rs = qrs.p;
+        q.job = qu.p;
+        q.depth = reinterpret_cast<int32_t *>(qu.p + cap);
+        q.best = reinterpret_cast<int32_t *>(qu.p + 2 * cap);
+        q.hit = reinterpret_cast<int32_t *>(qu.p + 3 * cap);
+        q.jseg = stats ? qu.p + 4 * cap : nullptr;
+        q.jdraw = stats ? qu.p + 5 * cap : nullptr;
+        q.count = count;
+        q.cap = (uint32_t)cap;
+    };
+    PathQueue qa, qb, qe;
+    bind(qa, d.cq_d, d.cq_rs, d.cq_u32, qw + 1);
+    bind(qb, d.xq_d, d.xq_rs, d.xq_u32, qw + 2);
+    bind(qe, d.gq_d, d.gq_rs, d.gq_u32, qw + 3);
+    ptk::WfArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.F = F;
+    A.F.fresh = F.njobs;
+    A.F.bvh_min_lanes = ctx->wf_min_lanes;
+    A.sky = fr.sky;
+    A.B = B;
+    A.cursor = qw;
+    const size_t lds_scan = fr.lds_bytes, lds_shade = fr.shade_lds_bytes, lds_mat = (size_t)F.nmat * sizeof(DevMat);
+    const uint32_t blocks_all = (F.njobs + PT_BLOCK - 1) / PT_BLOCK;
+    const uint32_t grid_scan = std::max(1u, std::min((uint32_t)(d.num_cu * d.blocks_per_cu_wf), blocks_all));
+    const uint32_t grid_pass = std::max(1u, std::min((uint32_t)(d.num_cu * 8), blocks_all));
+    const int levels = std::max(0, fr.cfg.max_depth);
+    if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + 2 * (size_t)levels + 1)) return rc;
+    if (int32_t rc = dev_events(d, d.ev_glass, d.n_glass + 3 * (size_t)levels + 2)) return rc;
+    auto timed = [&](std::vector<EventPair> &v, size_t &n, auto &&launch) -> int32_t {
+        EventPair &e = v[n++];
+        HIP_TRY(hipEventRecord(e.a, d.stream));
+        launch();
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e.b, d.stream));
+        return PT_OK;
+    };
+    auto scan_pass = [&](int mode) -> int32_t {
+        HIP_TRY(hipMemsetAsync(qw, 0, sizeof(unsigned int), d.stream));
+        if (d.trace_is_split.size() <= d.n_trace) d.trace_is_split.resize(d.n_trace + 1);
+        d.trace_is_split[d.n_trace] = 0;
+        return timed(d.ev_trace, d.n_trace, [&] {
+            if (bvh) {
+                if (mode == 0) {
+                    if (verify) hipLaunchKernelGGL((ptk::wf_traverse_kernel<0, true>), dim3(grid_scan), dim3(PT_BLOCK), lds_scan, d.stream, A);
+                    else hipLaunchKernelGGL((ptk::wf_traverse_kernel<0, false>), dim3(grid_scan), dim3(PT_BLOCK), lds_scan, d.stream, A);
+                } else {
+                    if (verify) hipLaunchKernelGGL((ptk::wf_traverse_kernel<1, true>), dim3(grid_scan), dim3(PT_BLOCK), lds_scan, d.stream, A);
+                    else hipLaunchKernelGGL((ptk::wf_traverse_kernel<1, false>), dim3(grid_scan), dim3(PT_BLOCK), lds_scan, d.stream, A);
+                }
+            } else {
+                if (mode == 0) {
+                    if (verify) hipLaunchKernelGGL((ptk::wf_scan_flat_kernel<0, true>), dim3(grid_scan), dim3(PT_BLOCK), lds_scan, d.stream, A);
+                    else hipLaunchKernelGGL((ptk::wf_scan_flat_kernel<0, false>), dim3(grid_scan), dim3(PT_BLOCK), lds_scan, d.stream, A);
+                } else {
+                    if (verify) hipLaunchKernelGGL((ptk::wf_scan_flat_kernel<1, true>), dim3(grid_scan), dim3(PT_BLOCK), lds_scan, d.stream, A);
+                    else hipLaunchKernelGGL((ptk::wf_scan_flat_kernel<1, false>), dim3(grid_scan), dim3(PT_BLOCK), lds_scan, d.stream, A);
+                }
+            }
+        });
+    };
+    // fresh jobs -> queue A
+    A.qin = qa;
+    A.qout = qb;
+    A.qexit = qe;
+    if (int32_t rc = timed(d.ev_glass, d.n_glass, [&] {
+            if (stats) hipLaunchKernelGGL(ptk::wf_init_kernel<true>, dim3(blocks_all), dim3(PT_BLOCK), 0, d.stream, A);
+            else hipLaunchKernelGGL(ptk::wf_init_kernel<false>, dim3(blocks_all), dim3(PT_BLOCK), 0, d.stream, A);
+        }))
+        return rc;
+    PathQueue cur_in = qa, cur_out = qb;
+    for (int level = 0; level < levels; level++) {
+        A.qin = cur_in;
+        A.qout = cur_out;
+        A.qexit = qe;
+        A.perm = nullptr;
+        if (ctx->wf_sort && level >= 1 && bvh) {
+            // primary rays leave raygen_kernel in pixel order, which is coherent; from the first bounce on the queue order
+            // means nothing, and the traversal pass takes the rays by direction octant and cell of the origin instead
+            A.bin_count = d.wf_bins.p;
+            A.bin_key = d.wf_key.p;
+            HIP_TRY(hipMemsetAsync(d.wf_bins.p, 0, (PT_WF_BINS + 1) * sizeof(uint32_t), d.stream));
+            if (int32_t rc = timed(d.ev_glass, d.n_glass, [&] {
+                    hipLaunchKernelGGL(ptk::wf_bin_count_kernel, dim3(grid_pass), dim3(PT_BLOCK), 0, d.stream, A);
+                    hipLaunchKernelGGL(ptk::wf_bin_scan_kernel, dim3(1), dim3(1024), 0, d.stream, A);
+                    hipLaunchKernelGGL(ptk::wf_bin_scatter_kernel, dim3(grid_pass), dim3(PT_BLOCK), 0, d.stream, A, d.wf_perm.p);
+                }))
+                return rc;
+            A.perm = d.wf_perm.p;
+            A.n_sorted = d.wf_bins.p + PT_WF_BINS;
+        }
+        if (int32_t rc = scan_pass(0)) return rc;
+        A.perm = nullptr;
+        HIP_TRY(hipMemsetAsync(cur_out.count, 0, sizeof(unsigned int), d.stream));
+        HIP_TRY(hipMemsetAsync(qe.count, 0, sizeof(unsigned int), d.stream));
+        if (int32_t rc = timed(d.ev_glass, d.n_glass, [&] {
+                if (stats) hipLaunchKernelGGL(ptk::wf_shade_kernel<true>, dim3(grid_pass), dim3(PT_BLOCK), lds_shade, d.stream, A);
+                else hipLaunchKernelGGL(ptk::wf_shade_kernel<false>, dim3(grid_pass), dim3(PT_BLOCK), lds_shade, d.stream, A);
+            }))
+            return rc;
+        if (fr.has_glass) {
+            A.qin = qe;
+            if (int32_t rc = scan_pass(1)) return rc;
+            if (int32_t rc = timed(d.ev_glass, d.n_glass, [&] {
+                    if (stats) hipLaunchKernelGGL(ptk::wf_exit_kernel<true>, dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, A);
+                    else hipLaunchKernelGGL(ptk::wf_exit_kernel<false>, dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, A);
+                }))
+                return rc;
+        }
+        std::swap(cur_in, cur_out);
+        // deep presets (the "final" mode asks for 80 levels): stop as soon as no path is left
+        if (level >= 8 && level % 4 == 0 && level + 1 < levels) {
+            unsigned int left = 0;
+            HIP_TRY(hipMemcpyAsync(&left, cur_in.count, sizeof left, hipMemcpyDeviceToHost, d.stream));
+            HIP_TRY(hipStreamSynchronize(d.stream));
+            if (left == 0) break;
+        }
     }
     return PT_OK;
 }
@@ -653,8 +815,9 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
             q.job = qu.p;
             q.depth = reinterpret_cast<int32_t *>(qu.p + cap);
             q.best = reinterpret_cast<int32_t *>(qu.p + 2 * cap);
-            q.jseg = fr.stats_on ? qu.p + 3 * cap : nullptr;
-            q.jdraw = fr.stats_on ? qu.p + 4 * cap : nullptr;
+            q.hit = reinterpret_cast<int32_t *>(qu.p + 3 * cap);
+            q.jseg = fr.stats_on ? qu.p + 4 * cap : nullptr;
+            q.jdraw = fr.stats_on ? qu.p + 5 * cap : nullptr;
             q.cap = (uint32_t)cap;
         };
         bind(B.glass, d.gq_d, d.gq_rs, d.gq_u32);
@@ -672,6 +835,9 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
                            d.ray.p, d.ray_rng.p, d.ray_ndraw.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(eg.b, d.stream));
+        if (fr.wavefront) {
+            if (int32_t rc = dev_step_wavefront(ctx, d, F, B)) return rc;
+        } else {
         auto launch_trace = [&](bool split, bool first) -> int32_t {
             TraceArgs A;
             A.F = F;
@@ -716,6 +882,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
                 B.cont.count = qw + 5;  // unused by the all-in-one form
                 if (int32_t rc = launch_trace(false, false)) return rc;
             }
+        }
         }
     }
     ptk::ResolveArgs R;
@@ -965,6 +1132,13 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     fr.split_rounds = 0;
     if ((sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY) && cfg->max_depth > 0)
         fr.split_rounds = fr.has_glass ? std::max(0, std::min(ctx->split_rounds, cfg->max_depth)) : (ctx->split_rounds > 0 ? 1 : 0);
+    {  // the wavefront form: BVH scenes by default, any scan with a pass form (bitmask, BVH) on request
+        const bool bvh = sd.scan == ptk::SCAN_BVH || sd.scan == ptk::SCAN_VERIFY_BVH;
+        const bool flat = sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY;
+        fr.wavefront = !ctx->profile_sections && ((bvh && ctx->pipeline != 0) || (flat && ctx->pipeline == 1));
+        if (fr.wavefront) fr.split_rounds = 0;
+        fr.shade_lds_bytes = (size_t)sd.Fs.nmat * sizeof(DevMat) + (sd.Fs.world_in_lds ? (size_t)sd.Fs.nobj * sizeof(DevObj) : 0);
+    }
     fr.cam = new_camera(scene->camera, cfg->width, cfg->height);
     fr.sky = make_sky(scene->sky);
     fr.ntx = (cfg->width + 31) / 32;
@@ -985,7 +1159,7 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     uint32_t chunk = cfg->spp_chunk > 0 ? (uint32_t)cfg->spp_chunk : 0;
     const uint32_t slots = std::max(1u, max_slots);
     // per job: 32 B radiance record + 58 B primary ray, and with split passes two path-state queues of 100 B per entry
-    const size_t job_bytes = 90 + (fr.split_rounds > 0 && fr.has_glass ? 200 : 0);
+    const size_t job_bytes = 90 + (fr.wavefront ? 330 : fr.split_rounds > 0 && fr.has_glass ? 220 : 0);
     if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * job_bytes));
     chunk = std::min<uint32_t>(chunk, (uint32_t)std::max(1, cfg->samples_per_px));
     chunk = std::min<uint32_t>(chunk, std::max(1u, 0x7fffffffu / slots));
@@ -1047,6 +1221,9 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
     }
     if (const char *e = std::getenv("PTCORE_PROFILE")) ctx->profile_sections = std::atoi(e) != 0;
     if (const char *e = std::getenv("PTCORE_SPLIT_ROUNDS")) ctx->split_rounds = std::max(0, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("PTCORE_PIPELINE")) ctx->pipeline = !std::strcmp(e, "wavefront") ? 1 : !std::strcmp(e, "mega") ? 0 : -1;
+    if (const char *e = std::getenv("PTCORE_WF_MIN_LANES")) ctx->wf_min_lanes = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("PTCORE_WF_SORT")) ctx->wf_sort = std::atoi(e);
     if (const char *e = std::getenv("PTCORE_BLOCKS_PER_CU")) {
         long c = std::atol(e);
         if (c >= 1 && c <= 8) ctx->max_blocks_per_cu = (int)c;
@@ -1095,6 +1272,8 @@ void pt_destroy(pt_ctx *ctx) {
         d.prof.release();
         d.bsph_diel.release(); d.bbox_diel.release();
         d.gq_d.release(); d.cq_d.release(); d.gq_rs.release(); d.cq_rs.release(); d.gq_u32.release(); d.cq_u32.release();
+        d.xq_d.release(); d.xq_rs.release(); d.xq_u32.release();
+        d.wf_perm.release(); d.wf_key.release(); d.wf_bins.release();
         for (EventPair &e : d.ev_glass) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         d.acc.release(); d.acc_seg.release(); d.acc_draw.release(); d.tiles_rgba.release();
         d.tiles_accum.release(); d.tiles_seg.release(); d.tiles_draw.release(); d.queue.release();
@@ -1241,6 +1420,27 @@ int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]) {
     out[6] = nested;
     out[7] = planes;
     return PT_OK;
+}
+
+// Runs div_selftest_kernel on device 0 of the context: `millions` x 10^6 operand pairs; returns the number of pairs
+// whose shared-reciprocal quotient differs from the IEEE division (must be 0), or a negative PT_ERR_* code.
+int64_t pt_debug_div_selftest(pt_ctx *ctx, int32_t millions, uint64_t seed) {
+    if (!ctx || millions <= 0) return -(int64_t)fail(PT_ERR_INVALID, "null context or no work");
+    Device &d = ctx->devs[0];
+    if (hipSetDevice(d.ordinal) != hipSuccess) return -(int64_t)fail(PT_ERR_HIP, "hipSetDevice");
+    unsigned long long *out = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&out), 8) != hipSuccess) return -(int64_t)fail(PT_ERR_HIP, "hipMalloc");
+    (void)hipMemsetAsync(out, 0, 8, d.own_stream);
+    const uint32_t per_thread = 1000;
+    const uint32_t blocks = (uint32_t)(((uint64_t)millions * 1000000ull + (uint64_t)per_thread * PT_BLOCK - 1) / ((uint64_t)per_thread * PT_BLOCK));
+    hipLaunchKernelGGL(ptk::div_selftest_kernel, dim3(blocks), dim3(PT_BLOCK), 0, d.own_stream, (unsigned long long)seed, per_thread, out);
+    unsigned long long bad = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, out, 8, hipMemcpyDeviceToHost, d.own_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d.own_stream);
+    (void)hipFree(out);
+    if (e != hipSuccess) return -(int64_t)fail(PT_ERR_HIP, std::string("div selftest: ") + hipGetErrorString(e));
+    return (int64_t)bad;
 }
 
 int64_t pt_debug_scan_mismatches(pt_ctx *ctx) {

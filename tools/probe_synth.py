@@ -15,5 +15,7 @@ for n in ns:
     t = time.time(); st = hip.render(sc, cfg, img, ctx=ctx); t1 = time.time() - t
     t = time.time(); st = hip.render(sc, cfg, img, ctx=ctx); dt = time.time() - t
     mm = L.pt_debug_scan_mismatches(ctx.handle) if os.environ.get("PTCORE_SCAN", "").startswith("verify") else -1
-    print("n=%d gen %.1fs first %.2fs | %dx%d spp %d: wall %.3fs trace %.1fms  Mseg/s %.1f  seg/samp %.2f  mismatches %d"
-          % (n, tg, t1, w, h, spp, dt, st["trace_ms"], st["segments"] / dt / 1e6, st["segments"] / st["samples"], mm), flush=True)
+    kms = st["trace_ms"] + st["glass_ms"]  # scan / traversal passes + shading passes (glass_kernel or the wavefront form's)
+    print("n=%d pipeline=%s gen %.1fs first %.2fs | %dx%d spp %d: wall %.3fs scan %.1fms shade %.1fms raygen %.1fms  kernel rate %.1f Mseg/s  wall rate %.1f Mseg/s  seg/samp %.2f  mismatches %d"
+          % (n, os.environ.get("PTCORE_PIPELINE", "default"), tg, t1, w, h, spp, dt, st["trace_ms"], st["glass_ms"], st["raygen_ms"],
+             st["segments"] / kms / 1e3, st["segments"] / dt / 1e6, st["segments"] / st["samples"], mm), flush=True)
