@@ -135,6 +135,8 @@ struct DevFrame {
     int32_t bvh_stack;                // traversal stack entries per lane (LDS)
     int32_t bvh_lds_nodes;            // top-level nodes of the main tree staged in LDS
     int32_t bvh_min_lanes;            // a traversal loop with fewer lanes still walking leaves them for the next trip
+    int32_t bvh_node_min;             // the node walk yields to the exact tests of waiting lanes below this many walking lanes
+    int32_t bvh_leaf_single;          // 1: one exact test per waiting lane and pass, then back to the walk
     uint32_t debug_drop;              // verify instantiations only (PTCORE_DEBUG_DROP): candidate bits cleared on purpose, so that
                                       // the disagreement counter can be shown to move
     int32_t broad_ok;    // 1: at most 32 sphere records and 32 box records -> candidate-bitmask scan usable;

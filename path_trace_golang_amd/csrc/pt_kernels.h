@@ -526,10 +526,11 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
 // candidate mask at a time, so no more registers than the single-group version), the dielectric mask of a
 // group is collected from the records on the scalar unit.  Between ~33 and ~200 objects this linear scan at
 // full lanes beats the hierarchy, whose walks diverge.
-template <bool PROF, bool DBG, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
-__device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr g_obj, SphPtr g_bs, BoxPtr g_bb, IdxPtr g_pl,
-                                                       const DevObj *s_obj, const int *s_kidx, const RayD &r, const Clip &clip,
-                                                       int mode, int &best, double &tmax, const ProfHooks &ph) {
+template <bool PROF, bool DBG, int MODE, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
+__device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr g_obj, const BroadLists<SphPtr, BoxPtr> &BL, IdxPtr g_pl,
+                                                       const DevObj *s_obj, const RayD &r, const Clip &clip,
+                                                       int mode_rt, int &best, double &tmax, const ProfHooks &ph) {
+    const int mode = MODE < 0 ? mode_rt : MODE;
     const double tmin = mode ? 0.0001 : 0.001;
     tmax = ptm::max_float64();
     best = -1;
@@ -568,12 +569,12 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
     const float aivxf = __builtin_fabsf(ivxf), aivyf = __builtin_fabsf(ivyf), aivzf = __builtin_fabsf(ivzf);
     const float noxf = -fox * ivxf, noyf = -foy * ivyf, nozf = -foz * ivzf;
 
-    for (int base = 0; base < F.n_bsph; base += 32) {
-        const int cnt = F.n_bsph - base < 32 ? F.n_bsph - base : 32;
+    for (int base = 0; base < BL.n_bsph; base += 32) {
+        const int cnt = BL.n_bsph - base < 32 ? BL.n_bsph - base : 32;
         PH_BEGIN(SEC_BROAD)
         uint32_t cs = 0, diel = 0;
         for (int k = 0; k < cnt; k++) {
-            const auto &s = g_bs[base + k];
+            const auto &s = BL.bs[base + k];
             const float ocx = fox - s.cx, ocy = foy - s.cy, ocz = foz - s.cz;
             const float b = __builtin_fmaf(ocx, fdx, __builtin_fmaf(ocy, fdy, ocz * fdz));
             const float tca = -b * inv_a;
@@ -593,7 +594,7 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
         while (__ballot(cs != 0) != 0) {
             if (cs != 0) {
                 PH_BEGIN(SEC_NSPH)
-                const int i = s_kidx[base + __builtin_ctz(cs)];
+                const int i = BL.kidx_s[base + __builtin_ctz(cs)];
                 cs &= cs - 1;
                 const DevObj &o = s_obj[i];
                 double t = 0;
@@ -607,14 +608,14 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
             }
         }
     }
-    if (F.n_bbox > 0) {
+    if (BL.n_bbox > 0) {
         const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
-        for (int base = 0; base < F.n_bbox; base += 32) {
-            const int cnt = F.n_bbox - base < 32 ? F.n_bbox - base : 32;
+        for (int base = 0; base < BL.n_bbox; base += 32) {
+            const int cnt = BL.n_bbox - base < 32 ? BL.n_bbox - base : 32;
             PH_BEGIN(SEC_BROAD)
             uint32_t cb = 0, diel = 0;
             for (int k = 0; k < cnt; k++) {
-                const auto &bx = g_bb[base + k];
+                const auto &bx = BL.bb[base + k];
                 PT_BOX_SLABS(bx, t0, t1)
                 const bool miss = t1 < t0;
                 cb = miss ? cb : (cb | (1u << k));
@@ -628,7 +629,7 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
             while (__ballot(cb != 0) != 0) {
                 if (cb != 0) {
                     PH_BEGIN(SEC_NBOX)
-                    const int i = s_kidx[F.n_bsph + base + __builtin_ctz(cb)];
+                    const int i = BL.kidx_b[base + __builtin_ctz(cb)];
                     cb &= cb - 1;
                     const DevObj &o = s_obj[i];
                     double t = 0;
@@ -742,12 +743,23 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     uint32_t n_leaf = 0;  // PROF only: object batches this lane went through
     PH_BEGIN(SEC_BROAD)
     const int n_start = __popcll(__ballot(1));
+    const bool single = F.bvh_leaf_single != 0;  // one exact test per waiting lane and pass (lanes that reach objects meanwhile join the next pass)
     for (;;) {
         const int walking = __popcll(__ballot(cur >= 0));
-        if (walking == 0) break;
-        if (walking < F.bvh_min_lanes && walking < n_start) break;  // stragglers carry on in the next trip
-        // ---- walk internal nodes until this lane holds objects to test (or has nothing left)
-        while (cur >= 0) {
+        const bool waiting = __ballot(pend != 0) != 0;
+        // stragglers carry on in the next trip (with no test pending: what waits is tested before the loop is left)
+        const bool leaving = walking < F.bvh_min_lanes && walking < n_start;
+        if (!waiting && (walking == 0 || leaving)) break;
+        // ---- walk internal nodes: a lane that reaches a node with pierced object slots waits (pend != 0) for the exact
+        // tests below.  The walk goes on as long as enough lanes are still walking; once fewer than F.bvh_node_min are and
+        // some lane waits, the waiting lanes get their tests first and rejoin the walk (waiting for the LAST lane to
+        // find its objects left the visit code running at a quarter of its lanes).
+        for (;;) {
+            const bool want = cur >= 0 && pend == 0;
+            const uint64_t wm = __ballot(want);
+            if (wm == 0 || leaving) break;
+            if (__popcll(wm) < F.bvh_node_min && __ballot(pend != 0) != 0) break;
+            if (want) {
             if (PROF) ph.lanes[SEC_NBOX]++;  // node visits (lane count)
             BvhNode nd;
             if (cur < F.bvh_lds_nodes) nd = lds_nodes[cur];  // top of the tree: LDS packet
@@ -822,14 +834,14 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 pend = oh;
                 pend_meta = meta;
                 pend_base = nd.obj_base;
-                break;
+            }
             }
         }
         // ---- exact tests of the objects gathered at the last node
         if (pend != 0) {
             PH_BEGIN(SEC_NSPH)
             if (PROF) n_leaf++;
-            while (pend != 0) {
+            do {
                 const uint32_t s = (uint32_t)__builtin_ctz(pend);
                 pend &= pend - 1;
                 const BvhObj &bo = bobjs[pend_base + (int)((pend_meta >> (2u * s)) & 3u)];
@@ -853,7 +865,7 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                     tmaxf = (float)(tmax - ts);
                     tmaxf += __builtin_fabsf(tmaxf) * 4.8e-7f;
                 }
-            }
+            } while (pend != 0 && (!single || leaving));
             PH_END(SEC_NSPH)
         }
     }
@@ -1215,8 +1227,9 @@ __device__ __forceinline__ uint32_t queue_reserve(uint32_t *count, bool push, ui
 // job; glass_kernel handles them together, and the paths that go on come back through the continuation queue.
 // The trace loop then never runs the dielectric branch, the exit search or its epilogue at 14 % of its lanes,
 // and no lane spends a whole trip through the scan on an exit search.
+// (launch bounds: the flat scans are asked to fit five waves per SIMD = 96 VGPRs, the BVH forms four = 128; the diagnostic form is not held to anything)
 template <bool STATS, bool PROF, int SCAN, bool SPLIT>
-__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const TraceArgs A) {
+__global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? 4 : 5) void trace_kernel(const TraceArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevFrame &F = A.F;
     const TraceBuffers &B = A.B;  // set-up and epilogue only; the loop reads the argument block through KA
@@ -1280,9 +1293,10 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const TraceArgs A) {
 
     // work items of this pass: continuation entries [0, n_cont), then fresh jobs [n_cont, n_cont + F.fresh)
     // (only the scans that have a split form ever see continuation entries)
-    constexpr bool CONT = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY);
+    constexpr bool CONT = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY || SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE);
     typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
-    const uint32_t n_cont = CONT ? *(ConstU32Ptr)(B.cont_in) : 0u;
+    const uint32_t n_cont_raw = CONT ? *(ConstU32Ptr)(B.cont_in) : 0u;
+    const uint32_t n_cont = n_cont_raw < B.cont.cap ? n_cont_raw : B.cont.cap;
     const uint32_t n_items = n_cont + F.fresh;
 
     // per-lane path state
@@ -1450,7 +1464,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const TraceArgs A) {
                     trav.live = false;  // a complete answer: whatever walk was pending is obsolete
                 } else {
                     if (WIDE)
-                        scan_broad_narrow_wide<PROF, VERIFY>(F, g_obj, g_bs, g_bb, g_pl, s_obj, lds_kidx, ray, clip, mode, best, tmax, ph);
+                        scan_broad_narrow_wide<PROF, VERIFY, SPLIT ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
                     else if (BITMASK)
                         scan_broad_narrow<PROF, VERIFY, SPLIT ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
                     else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
@@ -1573,7 +1587,10 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const TraceArgs A) {
                 } else {
                     g_cur += np;
                 }
-                if (to_glass) {
+                if (to_glass && slot >= gq->cap) {  // cannot happen (queues hold every job plus every window): fail loudly, write nothing
+                    atomicAdd(KA->B.counters + 19, 1ull);
+                    active = false;
+                } else if (to_glass) {
                     const size_t qc = gq->cap;
                     gq->d[slot] = ox;
                     gq->d[qc + slot] = oy;
@@ -1598,7 +1615,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const TraceArgs A) {
         SEC_END(SEC_ITER)
     }
     if (SPLIT) {  // what is left of this wave's window stays empty
-        for (uint32_t s = g_cur + lane; s < g_end; s += PT_WAVE) B.glass.job[s] = PT_HOLE;
+        for (uint32_t s = g_cur + lane; s < g_end && s < B.glass.cap; s += PT_WAVE) B.glass.job[s] = PT_HOLE;
     }
 #undef KA
 #undef PT_DRAW
@@ -1642,8 +1659,9 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(const TraceArgs A) {
 // to the next level (renderer.go:375-403).  Paths that go on are appended to the continuation queue, paths that end
 // write their radiance record (always zero here: glass emits nothing).  One entry per lane, grid-stride.
 // VERIFY: the exit search is also done by the plain object-by-object loop and disagreements are counted.
-template <bool STATS, bool VERIFY>
-__global__ __launch_bounds__(PT_BLOCK) void glass_kernel(const DevFrame F, const TraceBuffers B) {
+// WIDE: more than 32 spheres or boxes in the scene: the exit search takes its (dielectric-only) records in groups of 32.
+template <bool STATS, bool VERIFY, bool WIDE>
+__global__ __launch_bounds__(PT_BLOCK, 5) void glass_kernel(const DevFrame F, const TraceBuffers B) {
     extern __shared__ __align__(16) unsigned char smem[];
     DevObj *lds_obj = reinterpret_cast<DevObj *>(smem);
     DevMat *lds_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
@@ -1672,7 +1690,8 @@ __global__ __launch_bounds__(PT_BLOCK) void glass_kernel(const DevFrame F, const
                                                   all_s, all_b, lds_kidx, lds_kidx + F.n_dsph};
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
     typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
-    const uint32_t n = *(ConstU32Ptr)(B.glass.count);
+    const uint32_t n_raw = *(ConstU32Ptr)(B.glass.count);
+    const uint32_t n = n_raw < B.glass.cap ? n_raw : B.glass.cap;
     uint32_t c_exit = 0, c_draw = 0, c_mismatch = 0, c_cont = 0;
     const size_t qg = B.glass.cap, qc = B.cont.cap;
     uint32_t q_cur = 0, q_end = 0;  // this wave's window of continuation slots (see trace_kernel: one atomic per window)
@@ -1736,7 +1755,8 @@ __global__ __launch_bounds__(PT_BLOCK) void glass_kernel(const DevFrame F, const
                     if (__ballot(!tame) != 0) {
                         scan_uniform(F, g_obj, ray, 1, ebest, etmax);
                     } else {
-                        scan_broad_narrow<false, VERIFY, 1>(F, g_obj, BL, g_pl, lds_obj, ray, clip, 1, ebest, etmax, ph);
+                        if (WIDE) scan_broad_narrow_wide<false, VERIFY, 1>(F, g_obj, BL, g_pl, lds_obj, ray, clip, 1, ebest, etmax, ph);
+                        else scan_broad_narrow<false, VERIFY, 1>(F, g_obj, BL, g_pl, lds_obj, ray, clip, 1, ebest, etmax, ph);
                         if (VERIFY) {
                             int best2;
                             double tmax2;
@@ -1785,7 +1805,9 @@ __global__ __launch_bounds__(PT_BLOCK) void glass_kernel(const DevFrame F, const
             } else {
                 q_cur += np;
             }
-            if (go_on) {
+            if (go_on && slot >= B.cont.cap) {
+                atomicAdd(B.counters + 19, 1ull);  // cannot happen; never write outside the queue
+            } else if (go_on) {
                 B.cont.d[slot] = ox;
                 B.cont.d[qc + slot] = oy;
                 B.cont.d[2 * qc + slot] = oz;
@@ -1803,7 +1825,7 @@ __global__ __launch_bounds__(PT_BLOCK) void glass_kernel(const DevFrame F, const
             }
         }
     }
-    for (uint32_t s = q_cur + lane; s < q_end; s += PT_WAVE) B.cont.job[s] = PT_HOLE;  // the rest of the window stays empty
+    for (uint32_t s = q_cur + lane; s < q_end && s < B.cont.cap; s += PT_WAVE) B.cont.job[s] = PT_HOLE;  // the rest of the window stays empty
     const uint32_t w_exit = wave_sum(c_exit), w_draw = wave_sum(c_draw), w_cont = wave_sum(c_cont);
     if (lane == 0) {
         if (w_exit) atomicAdd(&B.counters[1], (unsigned long long)w_exit);

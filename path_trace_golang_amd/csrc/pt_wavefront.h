@@ -77,7 +77,8 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_bin_count_kernel(const WfArgs A) 
     __shared__ uint32_t hist[PT_WF_BINS];
     typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
     const PathQueue &Q = A.qin;
-    const uint32_t n = *(ConstU32Ptr)(Q.count);
+    const uint32_t n_count = *(ConstU32Ptr)(Q.count);
+    const uint32_t n = n_count < Q.cap ? n_count : Q.cap;
     const size_t qc = Q.cap;
     for (uint32_t k = threadIdx.x; k < PT_WF_BINS; k += PT_BLOCK) hist[k] = 0;
     __syncthreads();
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(1024) void wf_bin_scan_kernel(const WfArgs A) {
 __global__ __launch_bounds__(PT_BLOCK) void wf_bin_scatter_kernel(const WfArgs A, uint32_t *perm) {
     __shared__ uint32_t hist[PT_WF_BINS];
     typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
-    const uint32_t n = *(ConstU32Ptr)(A.qin.count);
+    const uint32_t n_count = *(ConstU32Ptr)(A.qin.count);
+    const uint32_t n = n_count < A.qin.cap ? n_count : A.qin.cap;
     for (uint32_t k = threadIdx.x; k < PT_WF_BINS; k += PT_BLOCK) hist[k] = 0;
     __syncthreads();
     uint32_t lo, hi;
@@ -165,13 +167,17 @@ __device__ __forceinline__ uint32_t window_push(QueueWindow &w, uint32_t *count,
     return slot;
 }
 __device__ __forceinline__ void window_close(const QueueWindow &w, const PathQueue &q, uint32_t lane) {
-    for (uint32_t s = w.cur + lane; s < w.end; s += PT_WAVE) q.job[s] = PT_HOLE;
+    for (uint32_t s = w.cur + lane; s < w.end && s < q.cap; s += PT_WAVE) q.job[s] = PT_HOLE;
 }
 
 __device__ __forceinline__ void queue_store(const PathQueue &q, uint32_t slot, double ox, double oy, double oz, double dx, double dy,
                                             double dz, double Tx, double Ty, double Tz, uint64_t rs, uint32_t job, int depth, int best,
-                                            uint32_t j_seg, uint32_t j_draw, bool stats) {
+                                            uint32_t j_seg, uint32_t j_draw, bool stats, unsigned long long *overflow) {
     const size_t qc = q.cap;
+    if (slot >= q.cap) {  // cannot happen (the host sizes the queues for every path plus every window); never write outside,
+        atomicAdd(overflow, 1ull);  // and make the frame fail instead of losing a path quietly
+        return;
+    }
     q.d[slot] = ox; q.d[qc + slot] = oy; q.d[2 * qc + slot] = oz;
     q.d[3 * qc + slot] = dx; q.d[4 * qc + slot] = dy; q.d[5 * qc + slot] = dz;
     q.d[6 * qc + slot] = Tx; q.d[7 * qc + slot] = Ty; q.d[8 * qc + slot] = Tz;
@@ -187,14 +193,14 @@ template <bool STATS>
 __global__ __launch_bounds__(PT_BLOCK) void wf_init_kernel(const WfArgs A) {
     const DevFrame &F = A.F;
     const TraceBuffers &B = A.B;
-    const uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
     uint32_t c_samples = 0, c_draw = 0;
-    if (i < F.njobs) {
+    // grid-stride: the two counters below get one atomic per wave of a few thousand, not one per 64 jobs
+    for (uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x; i < F.njobs; i += gridDim.x * PT_BLOCK) {
         const uint32_t nd = B.ray_ndraw[i];
         uint32_t job = PT_HOLE;
         if (nd != 0xffffu) {
-            c_samples = 1;
-            c_draw = nd;
+            c_samples++;
+            c_draw += nd;
             if (F.max_depth <= 0) {  // rayColorOpt returns black before any scan (renderer.go:287-289)
                 reinterpret_cast<double4 *>(B.L)[i] = make_double4(0.0, 0.0, 0.0, 0.0);
                 if (STATS) { B.job_seg[i] = 0; B.job_draw[i] = nd; }
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_init_kernel(const WfArgs A) {
                 job = i;
                 const size_t nj = F.njobs;
                 queue_store(A.qin, i, B.ray[i], B.ray[nj + i], B.ray[2 * nj + i], B.ray[3 * nj + i], B.ray[4 * nj + i], B.ray[5 * nj + i], 1.0,
-                            1.0, 1.0, B.ray_rng[i], i, F.max_depth, -1, 0u, nd, STATS);
+                            1.0, 1.0, B.ray_rng[i], i, F.max_depth, -1, 0u, nd, STATS, B.counters + 19);
             }
         }
         if (job == PT_HOLE) A.qin.job[i] = PT_HOLE;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_init_kernel(const WfArgs A) {
         if (w_d) atomicAdd(&B.counters[2], (unsigned long long)w_d);
         if (w_s) atomicAdd(&B.counters[3], (unsigned long long)w_s);
     }
-    if (i == 0) *A.qin.count = F.njobs;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *A.qin.count = F.njobs;
 }
 
 // Closest hit (MODE 0) or exit search (MODE 1) of every path in A.qin: best and tmax are written into the entry.
@@ -239,7 +245,8 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(const WfArgs A) {
     const ConstObjPtr g_obj = (ConstObjPtr)(B.objs);
     const ConstIdxPtr g_pl = (ConstIdxPtr)(B.plane_idx);
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
-    const uint32_t n_items = A.perm ? *(ConstU32Ptr)(A.n_sorted) : *(ConstU32Ptr)(Q.count);
+    const uint32_t n_count = *(ConstU32Ptr)(Q.count);
+    const uint32_t n_items = A.perm ? *(ConstU32Ptr)(A.n_sorted) : (n_count < Q.cap ? n_count : Q.cap);
     const size_t qc = Q.cap;
 
     bool have = false;
@@ -365,7 +372,8 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_scan_flat_kernel(const WfArgs A) 
     const BroadLists<ConstSphPtr, ConstBoxPtr> BL{(ConstSphPtr)B.bsph, (ConstBoxPtr)B.bbox, F.n_bsph, F.n_bbox, F.sph_all, F.box_all,
                                                   F.sph_diel, F.box_diel, lds_kidx, lds_kidx + F.n_bsph};
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
-    const uint32_t n = *(ConstU32Ptr)(Q.count);
+    const uint32_t n_count = *(ConstU32Ptr)(Q.count);
+    const uint32_t n = n_count < Q.cap ? n_count : Q.cap;
     const size_t qc = Q.cap;
     uint32_t c_mismatch = 0;
     const ProfHooks ph{nullptr, nullptr, nullptr, lane, nullptr};
@@ -429,7 +437,8 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_shade_kernel(const WfArgs A) {
     const DevObj *const s_obj = world_in_lds ? lds_obj : B.objs;
     typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
-    const uint32_t n = *(ConstU32Ptr)(Q.count);
+    const uint32_t n_count = *(ConstU32Ptr)(Q.count);
+    const uint32_t n = n_count < Q.cap ? n_count : Q.cap;
     const size_t qc = Q.cap;
     uint32_t c_seg = 0, c_draw = 0, c_exit = 0;
     QueueWindow w_out, w_exit;
@@ -492,9 +501,9 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_shade_kernel(const WfArgs A) {
             }
         }
         const uint32_t s_out = window_push(w_out, A.qout.count, go_on, lane, PT_CONT_BLOCK);
-        if (go_on) queue_store(A.qout, s_out, ox, oy, oz, dx, dy, dz, Tx, Ty, Tz, rs, job, depth, -1, j_seg, j_draw, STATS);
+        if (go_on) queue_store(A.qout, s_out, ox, oy, oz, dx, dy, dz, Tx, Ty, Tz, rs, job, depth, -1, j_seg, j_draw, STATS, B.counters + 19);
         const uint32_t s_ex = window_push(w_exit, A.qexit.count, to_exit, lane, PT_QUEUE_BLOCK);
-        if (to_exit) queue_store(A.qexit, s_ex, ox, oy, oz, dx, dy, dz, Tx, Ty, Tz, rs, job, depth, exit_mat, j_seg, j_draw, STATS);
+        if (to_exit) queue_store(A.qexit, s_ex, ox, oy, oz, dx, dy, dz, Tx, Ty, Tz, rs, job, depth, exit_mat, j_seg, j_draw, STATS, B.counters + 19);
     }
     window_close(w_out, A.qout, lane);
     window_close(w_exit, A.qexit, lane);
@@ -525,7 +534,8 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_exit_kernel(const WfArgs A) {
     }
     typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
-    const uint32_t n = *(ConstU32Ptr)(Q.count);
+    const uint32_t n_count = *(ConstU32Ptr)(Q.count);
+    const uint32_t n = n_count < Q.cap ? n_count : Q.cap;
     const size_t qc = Q.cap;
     uint32_t c_draw = 0;
     QueueWindow w_out;
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_exit_kernel(const WfArgs A) {
             }
         }
         const uint32_t s_out = window_push(w_out, A.qout.count, go_on, lane, PT_CONT_BLOCK);
-        if (go_on) queue_store(A.qout, s_out, ox, oy, oz, dx, dy, dz, Tx, Ty, Tz, rs, job, depth, -1, j_seg, j_draw, STATS);
+        if (go_on) queue_store(A.qout, s_out, ox, oy, oz, dx, dy, dz, Tx, Ty, Tz, rs, job, depth, -1, j_seg, j_draw, STATS, B.counters + 19);
     }
     window_close(w_out, A.qout, lane);
     const uint32_t w_draw = wave_sum(c_draw);

@@ -473,6 +473,8 @@ TraceFn pick_trace(bool stats, bool prof, int scan, bool split = false) {
     }
     if (split) {
         if (scan == SCAN_VERIFY) return stats ? trace_kernel<true, false, SCAN_VERIFY, true> : trace_kernel<false, false, SCAN_VERIFY, true>;
+        if (scan == SCAN_BROAD_WIDE) return stats ? trace_kernel<true, false, SCAN_BROAD_WIDE, true> : trace_kernel<false, false, SCAN_BROAD_WIDE, true>;
+        if (scan == SCAN_VERIFY_WIDE) return stats ? trace_kernel<true, false, SCAN_VERIFY_WIDE, true> : trace_kernel<false, false, SCAN_VERIFY_WIDE, true>;
         return stats ? trace_kernel<true, false, SCAN_BROAD, true> : trace_kernel<false, false, SCAN_BROAD, true>;
     }
     switch (scan) {
@@ -489,8 +491,10 @@ TraceFn pick_trace(bool stats, bool prof, int scan, bool split = false) {
 using GlassFn = void (*)(const DevFrame, const TraceBuffers);
 GlassFn pick_glass(bool stats, int scan) {
     using namespace ptk;
-    if (scan == SCAN_VERIFY) return stats ? glass_kernel<true, true> : glass_kernel<false, true>;
-    return stats ? glass_kernel<true, false> : glass_kernel<false, false>;
+    if (scan == SCAN_VERIFY) return stats ? glass_kernel<true, true, false> : glass_kernel<false, true, false>;
+    if (scan == SCAN_BROAD_WIDE) return stats ? glass_kernel<true, false, true> : glass_kernel<false, false, true>;
+    if (scan == SCAN_VERIFY_WIDE) return stats ? glass_kernel<true, true, true> : glass_kernel<false, true, true>;
+    return stats ? glass_kernel<true, false, false> : glass_kernel<false, false, false>;
 }
 
 int32_t dev_events(Device &d, std::vector<EventPair> &v, size_t need) {
@@ -664,7 +668,10 @@ int32_t dev_step_wavefront(pt_ctx *ctx, Device &d, const DevFrame &F, const Trac
     const size_t lds_scan = fr.lds_bytes, lds_shade = fr.shade_lds_bytes, lds_mat = (size_t)F.nmat * sizeof(DevMat);
     const uint32_t blocks_all = (F.njobs + PT_BLOCK - 1) / PT_BLOCK;
     const uint32_t grid_scan = std::max(1u, std::min((uint32_t)(d.num_cu * d.blocks_per_cu_wf), blocks_all));
-    const uint32_t grid_pass = std::max(1u, std::min((uint32_t)(d.num_cu * 8), blocks_all));
+    // shading passes: four blocks per CU.  Their waves append to the next level's queue in windows of PT_CONT_BLOCK slots
+    // (one atomic per window: a pass this short cannot afford more on one address); shade + exit pass together leave at most
+    // 2 x (num_cu x 16 waves) x PT_CONT_BLOCK slots empty, which is the margin the queues are allocated with.
+    const uint32_t grid_pass = std::max(1u, std::min((uint32_t)(d.num_cu * 4), blocks_all));
     const int levels = std::max(0, fr.cfg.max_depth);
     if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + 2 * (size_t)levels + 1)) return rc;
     if (int32_t rc = dev_events(d, d.ev_glass, d.n_glass + 3 * (size_t)levels + 2)) return rc;
@@ -705,8 +712,8 @@ int32_t dev_step_wavefront(pt_ctx *ctx, Device &d, const DevFrame &F, const Trac
     A.qout = qb;
     A.qexit = qe;
     if (int32_t rc = timed(d.ev_glass, d.n_glass, [&] {
-            if (stats) hipLaunchKernelGGL(ptk::wf_init_kernel<true>, dim3(blocks_all), dim3(PT_BLOCK), 0, d.stream, A);
-            else hipLaunchKernelGGL(ptk::wf_init_kernel<false>, dim3(blocks_all), dim3(PT_BLOCK), 0, d.stream, A);
+            if (stats) hipLaunchKernelGGL(ptk::wf_init_kernel<true>, dim3(std::min(blocks_all, (uint32_t)d.num_cu * 8u)), dim3(PT_BLOCK), 0, d.stream, A);
+            else hipLaunchKernelGGL(ptk::wf_init_kernel<false>, dim3(std::min(blocks_all, (uint32_t)d.num_cu * 8u)), dim3(PT_BLOCK), 0, d.stream, A);
         }))
         return rc;
     PathQueue cur_in = qa, cur_out = qb;
@@ -955,6 +962,7 @@ int32_t dev_collect(Device &d, pt_stats *st, int slot) {
     if (d.nlocal == 0) return PT_OK;
     unsigned long long c[24] = {};
     HIP_TRY(hipMemcpy(c, d.counters.p, sizeof c, hipMemcpyDeviceToHost));
+    if (c[19]) return fail(PT_ERR_STATE, "internal: a path-state queue overflowed (" + std::to_string(c[19]) + " paths lost); the frame is invalid");
     g_mismatches += c[4];
     if (c[4]) std::memcpy(g_mismatch_sample, c + 8, sizeof g_mismatch_sample);
     st->segments += c[0];
@@ -1101,6 +1109,10 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     F.debug_drop = 0;  // PTCORE_DEBUG_DROP=<mask>: the verify instantiations of the bitmask scans lose these candidate bits
     if (const char *e = std::getenv("PTCORE_DEBUG_DROP")) F.debug_drop = (uint32_t)std::strtoul(e, nullptr, 0);
     if (const char *e = std::getenv("PTCORE_BVH_MIN_LANES")) F.bvh_min_lanes = std::max(0, std::min(64, std::atoi(e)));
+    F.bvh_leaf_single = 1;
+    if (const char *e = std::getenv("PTCORE_BVH_LEAF_SINGLE")) F.bvh_leaf_single = std::atoi(e) != 0;
+    F.bvh_node_min = 16;
+    if (const char *e = std::getenv("PTCORE_BVH_NODE_MIN")) F.bvh_node_min = std::max(0, std::min(65, std::atoi(e)));
     if (big && F.bvh_root == 0 && stack_bytes < 40960)
         F.bvh_lds_nodes = (int32_t)std::min<size_t>((40960 - stack_bytes) / sizeof(BvhNode), (size_t)F.bvh_main_nodes);
     sd.lds_bytes = big ? stack_bytes + (size_t)F.bvh_lds_nodes * sizeof(BvhNode)
@@ -1130,7 +1142,8 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     for (const DevObj &o : sd.world) fr.has_glass = fr.has_glass || (o.kind & 0x100);
     // split passes: the bitmask scan of reference-sized scenes; a path has at most max_depth dielectric bounces
     fr.split_rounds = 0;
-    if ((sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY) && cfg->max_depth > 0)
+    if ((sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY || sd.scan == ptk::SCAN_BROAD_WIDE || sd.scan == ptk::SCAN_VERIFY_WIDE) &&
+        cfg->max_depth > 0)
         fr.split_rounds = fr.has_glass ? std::max(0, std::min(ctx->split_rounds, cfg->max_depth)) : (ctx->split_rounds > 0 ? 1 : 0);
     {  // the wavefront form: BVH scenes by default, any scan with a pass form (bitmask, BVH) on request
         const bool bvh = sd.scan == ptk::SCAN_BVH || sd.scan == ptk::SCAN_VERIFY_BVH;

@@ -5,11 +5,11 @@
 # PMC passes (each its own run, counters only, as the pool requires) use a short
 # workload with the SAME launch shape as the full run (2 trace launches, the first a full chunk).
 set -o pipefail
-TAG=${1:-r01}; shift
+TAG=${1:-r02}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-SHORT="--spp 200 --steps 1 --warmup 0 --no-cpu-baseline"   # 2 launches of one full 100-spp chunk each
+SHORT="--spp 192 --steps 1 --warmup 0 --no-cpu-baseline"   # two full chunks and a short one, the launch shapes of the full run
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_under_trace.json 2> $OUT/trace.err || exit 1
 echo "trace pass done"
 i=0
