@@ -247,13 +247,21 @@ inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> 
         int ni = 0, no = 0;
         for (int s = 0; s < WIDTH; s++) {
             if (s >= ns) {  // empty slot: never flagged in the masks; the box is a far-away point
-                for (int k = 0; k < 3; k++) { nd.lo[k][s] = 3.0e38f; nd.hi[k][s] = 3.0e38f; }
+                for (int k = 0; k < 3; k++) { nd.c[k][s] = 3.0e38f; nd.h[k][s] = 0.0f; }
                 continue;
             }
             const detail::BinNode &c = bl.bin[(size_t)slot[s]];
             for (int k = 0; k < 3; k++) {
-                nd.lo[k][s] = detail::down(c.box.lo[k] - margin);
-                nd.hi[k][s] = detail::up(c.box.hi[k] + margin);
+                const double lo = c.box.lo[k] - margin, hi = c.box.hi[k] + margin;
+                const float cf = (float)(0.5 * lo + 0.5 * hi);
+                if (lo == lo && hi == hi && std::isfinite(cf)) {
+                    nd.c[k][s] = cf;
+                    nd.h[k][s] = detail::up(std::max((double)cf - lo, hi - (double)cf));  // [c - h, c + h] holds [lo, hi]
+                    if (!(nd.h[k][s] == nd.h[k][s])) nd.h[k][s] = INFINITY;
+                } else {  // absurd or non-finite bounds: the slab constrains nothing
+                    nd.c[k][s] = 0.0f;
+                    nd.h[k][s] = INFINITY;
+                }
             }
             if (c.obj >= 0) {
                 ranks |= (uint32_t)no << (2 * s);

@@ -71,14 +71,15 @@ struct alignas(16) BroadBox {
 static_assert(sizeof(BroadBox) == 32, "BroadBox layout");
 
 // BVH node for scenes beyond the candidate bitmasks: four slots, each an internal node, one object or
-// empty, with the slot's FP32 box (inflated, rounded outward) stored slot-minor so one 16-byte load
-// brings the same bound of all four.  Nodes are numbered breadth-first: the internal children of a
+// empty, with the slot's FP32 box (inflated, rounded outward; as centre and half extent) stored slot-minor so one
+// 16-byte load brings the same number of all four.  Nodes are numbered breadth-first: the internal children of a
 // node are node_base + rank, its object children bvh_objs[obj_base + rank].
 //   meta bits 0-7: rank of slot s within its kind at bits [2s, 2s+2); 8-11: slot is an internal node;
 //   12-15: slot is an object; 16-19: slot is NOT an internal node (complement of 8-11).
 struct alignas(128) BvhNode {   // one 128-byte cache line per node (112 bytes used)
-    float lo[3][4];   // [axis][slot]
-    float hi[3][4];
+    float c[3][4];    // [axis][slot] centre of the slot's inflated box
+    float h[3][4];    // half extent, rounded up so that [c - h, c + h] holds it (the slab test is then three fma per axis and slot
+                      // pair, no min / max to order the planes: see PT_BOX_SLABS in pt_kernels.h)
     int32_t node_base;
     int32_t obj_base;
     uint32_t meta;

@@ -42,6 +42,8 @@ namespace ptk {
 
 using namespace ptd;
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the packed FP32 instructions (v_pk_fma_f32)
+
 #define PT_WAVE 64
 #define PT_BLOCK 256
 #define PT_QUEUE_BLOCK 256u     // glass-queue slots a wave of trace_kernel reserves per atomic
@@ -733,6 +735,11 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     // component, which unconstrains the slab)
     const float inflf = CAREFUL ? (float)clip.infl * 1.0001f : 0.0f;
     const float exf = inflf * __builtin_fabsf(ivxf), eyf = inflf * __builtin_fabsf(ivyf), ezf = inflf * __builtin_fabsf(ivzf);
+    const v2f ivx2 = {ivxf, ivxf}, ivy2 = {ivyf, ivyf}, ivz2 = {ivzf, ivzf};
+    const v2f nox2 = {noxf, noxf}, noy2 = {noyf, noyf}, noz2 = {nozf, nozf};
+    const v2f aivx2 = {__builtin_fabsf(ivxf), __builtin_fabsf(ivxf)}, aivy2 = {__builtin_fabsf(ivyf), __builtin_fabsf(ivyf)},
+              aivz2 = {__builtin_fabsf(ivzf), __builtin_fabsf(ivzf)};
+    const v2f ex2 = {exf, exf}, ey2 = {eyf, eyf}, ez2 = {ezf, ezf};
     float tmaxf = (float)(tmax - ts);
     tmaxf += __builtin_fabsf(tmaxf) * 4.8e-7f;  // >= tmax - ts (MaxFloat64 becomes +inf)
     int sp = resume ? S.sp : 0;
@@ -766,21 +773,37 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
             else nd = nodes[cur];                            // below: HBM / L2
             float t0[4];
             uint32_t hb = 0;
+            // slab parameters of the four slots from centre and half extent, two slots per packed instruction:
+            // tc = c*iv - o*iv, tn = tc - h*|iv|, tf = tc + h*|iv| (three v_pk_fma_f32 per axis and pair; the lo / hi form
+            // cost two v_fma_f32 and a 4-cycle v_min / v_max pair per axis and SLOT)
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const float tax = __builtin_fmaf(nd.lo[0][s], ivxf, noxf), tbx = __builtin_fmaf(nd.hi[0][s], ivxf, noxf);
-                const float tay = __builtin_fmaf(nd.lo[1][s], ivyf, noyf), tby = __builtin_fmaf(nd.hi[1][s], ivyf, noyf);
-                const float taz = __builtin_fmaf(nd.lo[2][s], ivzf, nozf), tbz = __builtin_fmaf(nd.hi[2][s], ivzf, nozf);
-                // v_min/v_max return the other operand for a NaN: a NaN slab (0 * inf) constrains nothing
-                float nx_ = __builtin_fminf(tax, tbx), ny_ = __builtin_fminf(tay, tby), nz_ = __builtin_fminf(taz, tbz);
-                float fx_ = __builtin_fmaxf(tax, tbx), fy_ = __builtin_fmaxf(tay, tby), fz_ = __builtin_fmaxf(taz, tbz);
-                if (CAREFUL) {
-                    nx_ -= exf; ny_ -= eyf; nz_ -= ezf;
-                    fx_ += exf; fy_ += eyf; fz_ += ezf;
+            for (int p = 0; p < 2; p++) {
+                const v2f cx = {nd.c[0][2 * p], nd.c[0][2 * p + 1]}, cy = {nd.c[1][2 * p], nd.c[1][2 * p + 1]},
+                          cz = {nd.c[2][2 * p], nd.c[2][2 * p + 1]};
+                const v2f hx = {nd.h[0][2 * p], nd.h[0][2 * p + 1]}, hy = {nd.h[1][2 * p], nd.h[1][2 * p + 1]},
+                          hz = {nd.h[2][2 * p], nd.h[2][2 * p + 1]};
+                const v2f tcx = __builtin_elementwise_fma(cx, ivx2, nox2), tcy = __builtin_elementwise_fma(cy, ivy2, noy2),
+                          tcz = __builtin_elementwise_fma(cz, ivz2, noz2);
+                v2f nx_, ny_, nz_, fx_, fy_, fz_;
+                if (CAREFUL) {  // every bound widened by the lane's own inflation (in parameter units: exf, eyf, ezf)
+                    const v2f thx = __builtin_elementwise_fma(hx, aivx2, ex2), thy = __builtin_elementwise_fma(hy, aivy2, ey2),
+                              thz = __builtin_elementwise_fma(hz, aivz2, ez2);
+                    nx_ = tcx - thx; ny_ = tcy - thy; nz_ = tcz - thz;
+                    fx_ = tcx + thx; fy_ = tcy + thy; fz_ = tcz + thz;
+                } else {
+                    nx_ = __builtin_elementwise_fma(-hx, aivx2, tcx); ny_ = __builtin_elementwise_fma(-hy, aivy2, tcy);
+                    nz_ = __builtin_elementwise_fma(-hz, aivz2, tcz);
+                    fx_ = __builtin_elementwise_fma(hx, aivx2, tcx); fy_ = __builtin_elementwise_fma(hy, aivy2, tcy);
+                    fz_ = __builtin_elementwise_fma(hz, aivz2, tcz);
                 }
-                t0[s] = __builtin_fmaxf(__builtin_fmaxf(nx_, ny_), __builtin_fmaxf(nz_, tminf));
-                const float t1 = __builtin_fminf(__builtin_fminf(fx_, fy_), __builtin_fminf(fz_, tmaxf));
-                hb |= (t1 < t0[s]) ? 0u : (1u << s);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int s = 2 * p + q;
+                    // v_min/v_max return the other operand for a NaN: a NaN slab (0 * inf) constrains nothing
+                    t0[s] = __builtin_fmaxf(__builtin_fmaxf(nx_[q], ny_[q]), __builtin_fmaxf(nz_[q], tminf));
+                    const float t1 = __builtin_fminf(__builtin_fminf(fx_[q], fy_[q]), __builtin_fminf(fz_[q], tmaxf));
+                    hb |= (t1 < t0[s]) ? 0u : (1u << s);
+                }
             }
             if (CAREFUL && !trust) {  // rays outside the analysed range visit everything
                 hb = 0xfu;

@@ -184,7 +184,7 @@ struct pt_ctx {
     DevBuf<double> f_accum;
     DevBuf<uint32_t> f_seg, f_draw;
     size_t l_budget_bytes = (size_t)48 << 30;  // per-chunk job buffers (radiance, primary rays, path-state queues): a sixth of the 288 GB
-    int pipeline = -1;     // PTCORE_PIPELINE=mega|wavefront: -1 = by scene (wavefront for BVH scenes)
+    int pipeline = -1;     // PTCORE_PIPELINE=mega|wavefront (default: the all-in-one loop)
     int wf_min_lanes = 40; // PTCORE_WF_MIN_LANES: the walk loop of a traversal pass is left for a refill below this many walking lanes
     int wf_sort = 0;       // PTCORE_WF_SORT=1: reorder the paths of a level by direction octant and origin cell
     int split_rounds = 2;  // PTCORE_SPLIT_ROUNDS: trace + glass pass pairs per chunk before the all-in-one pass (bitmask scan only)
@@ -1145,10 +1145,11 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     if ((sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY || sd.scan == ptk::SCAN_BROAD_WIDE || sd.scan == ptk::SCAN_VERIFY_WIDE) &&
         cfg->max_depth > 0)
         fr.split_rounds = fr.has_glass ? std::max(0, std::min(ctx->split_rounds, cfg->max_depth)) : (ctx->split_rounds > 0 ? 1 : 0);
-    {  // the wavefront form: BVH scenes by default, any scan with a pass form (bitmask, BVH) on request
+    {  // the wavefront form: on request (PTCORE_PIPELINE=wavefront), for the scans that have a pass form (bitmask, BVH).
+       // Measured slower than the all-in-one loop in every regime, so it is the A/B, not the default.
         const bool bvh = sd.scan == ptk::SCAN_BVH || sd.scan == ptk::SCAN_VERIFY_BVH;
         const bool flat = sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY;
-        fr.wavefront = !ctx->profile_sections && ((bvh && ctx->pipeline != 0) || (flat && ctx->pipeline == 1));
+        fr.wavefront = !ctx->profile_sections && ctx->pipeline == 1 && (bvh || flat);
         if (fr.wavefront) fr.split_rounds = 0;
         fr.shade_lds_bytes = (size_t)sd.Fs.nmat * sizeof(DevMat) + (sd.Fs.world_in_lds ? (size_t)sd.Fs.nobj * sizeof(DevObj) : 0);
     }
@@ -1398,12 +1399,17 @@ int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]) {
         for (int s = 0; s < 4; s++) {
             if (!((intm | objm) & (1u << s))) continue;
             const int rank = (int)((nd.meta >> (2 * s)) & 3u);
-            for (int k = 0; k < 3; k++)
-                if (nd.lo[k][s] < it.lo[k] || nd.hi[k][s] > it.hi[k]) nested++;
+            // (centre / half-extent boxes are rounded one by one: a child's may stick out of its parent's by a few ulps, which
+            // the walk does not care about -- every box holds its own content, that is all it relies on)
+            for (int k = 0; k < 3; k++) {
+                const float slo = nd.c[k][s] - nd.h[k][s], shi = nd.c[k][s] + nd.h[k][s];
+                const float tol = 8.0f * 1.1920929e-7f * std::max(std::fabs(slo), std::fabs(shi));
+                if (slo < it.lo[k] - tol || shi > it.hi[k] + tol) nested++;
+            }
             if (intm & (1u << s)) {
                 Item c;
                 c.node = nd.node_base + rank;
-                for (int k = 0; k < 3; k++) { c.lo[k] = nd.lo[k][s]; c.hi[k] = nd.hi[k][s]; }
+                for (int k = 0; k < 3; k++) { c.lo[k] = nd.c[k][s] - nd.h[k][s]; c.hi[k] = nd.c[k][s] + nd.h[k][s]; }
                 if (c.node <= it.node || c.node >= (int32_t)b.nodes.size()) { nested++; continue; }
                 st.push_back(c);
             } else {
@@ -1413,7 +1419,8 @@ int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]) {
                 seen[(size_t)oi]++;
                 const ptbvh::Aabb bb = ptbvh::object_bounds(world[(size_t)oi]);
                 for (int a = 0; a < 3; a++)
-                    if ((double)nd.lo[a][s] > bb.lo[a] - margin * 0.999 || (double)nd.hi[a][s] < bb.hi[a] + margin * 0.999) { outside++; break; }
+                    if ((double)nd.c[a][s] - (double)nd.h[a][s] > bb.lo[a] - margin * 0.999 ||
+                        (double)nd.c[a][s] + (double)nd.h[a][s] < bb.hi[a] + margin * 0.999) { outside++; break; }
             }
         }
     }
