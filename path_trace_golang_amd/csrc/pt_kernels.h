@@ -1009,6 +1009,112 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_kernel(const DevFrame F, cons
     ray_ndraw[myjob] = (uint16_t)(nd < 0xfffeu ? nd : 0xfffeu);
 }
 
+// Ray generation for a thin-lens camera (lens_radius > 0).  The lens sample is a rejection loop (randomInUnitSphere,
+// math.go:74-84: 1.9 attempts on average, the unluckiest of 64 lanes needs 6-7), and in raygen_kernel a wave waits for its
+// unluckiest lane on every job: 2.75 ms of a 4.4 ms launch.  Here a wave owns PT_RG_ROWS rows of 64 jobs and a lane walks
+// down its column: as soon as one job's sample is accepted it starts on the job below, so the wave waits for the largest
+// SUM of attempts over a column (~14 for four rows instead of 4 x 6.5).  Three phases, all per-job data through LDS so
+// that every global store is a full coalesced row: (A) lockstep: stream init, u, v, the point on the focus plane;
+// (B) the rejection walk; (C) lockstep: lens offset, ray, stores.  Same draws in the same order per job as
+// raygen_kernel (renderer.go:182-183, camera.go:60-74).
+#define PT_RG_ROWS 4
+__global__ __launch_bounds__(PT_BLOCK) void raygen_lens_kernel(const DevFrame F, const DevCamera cam, double *__restrict__ ray,
+                                                                 unsigned long long *__restrict__ ray_rng,
+                                                                 uint16_t *__restrict__ ray_ndraw) {
+    // per job, plane by plane (lane-minor: conflict-free): the point on the focus plane, the accepted lens sample, the
+    // stream state and the draws so far (0xffffffff: pixel outside the frame, or no such job); 52 KB: three blocks per CU
+    __shared__ double s_ax[PT_RG_ROWS][PT_BLOCK], s_ay[PT_RG_ROWS][PT_BLOCK], s_az[PT_RG_ROWS][PT_BLOCK];
+    __shared__ double s_rx[PT_RG_ROWS][PT_BLOCK], s_ry[PT_RG_ROWS][PT_BLOCK];
+    __shared__ unsigned long long s_rs[PT_RG_ROWS][PT_BLOCK];
+    __shared__ uint32_t s_nd[PT_RG_ROWS][PT_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (PT_WAVE - 1);
+    const uint32_t wave = (blockIdx.x * PT_BLOCK + tid) >> 6;
+    const uint32_t row0 = wave * PT_RG_ROWS;  // rows of 64 consecutive jobs
+    // ---- A: everything up to the lens sample, row by row
+#pragma unroll
+    for (int k = 0; k < PT_RG_ROWS; k++) {
+        const uint32_t myjob = (row0 + (uint32_t)k) * 64u + lane;
+        uint32_t nd0 = 0xffffffffu;
+        if (myjob < F.njobs) {
+            const uint32_t p = myjob & 63u;
+            const uint32_t q = myjob >> 6;
+            const uint32_t blk = q / F.S;
+            const uint32_t sl = q - blk * F.S;
+            const uint32_t lt = blk >> 4, sb = blk & 15u;
+            const uint32_t t = (uint32_t)F.shard_index + lt * (uint32_t)F.shard_count;
+            const uint32_t ty = t / (uint32_t)F.ntx, tx = t - ty * (uint32_t)F.ntx;
+            const uint32_t x = tx * 32u + (sb & 3u) * 8u + (p & 7u);
+            const uint32_t y = ty * 32u + (sb >> 2) * 8u + (p >> 3);
+            if (x < (uint32_t)F.width && y < (uint32_t)F.height) {
+                const uint64_t pixel = (uint64_t)y * (uint64_t)(uint32_t)F.width + (uint64_t)x;
+                uint64_t rs = ptm::stream_init(F.seed_key, pixel, (uint64_t)(F.s0 + sl));
+                const double xi_u = ptm::stream_next(rs);
+                const double xi_v = ptm::stream_next(rs);
+                const double u = ((double)x + xi_u) * F.inv_width;
+                const double vv = ((F.height_m1 - (double)y) + xi_v) * F.inv_height;
+                const double tx_ = cam.lower_left[0] + cam.horizontal[0] * u;
+                const double ty_ = cam.lower_left[1] + cam.horizontal[1] * u;
+                const double tz_ = cam.lower_left[2] + cam.horizontal[2] * u;
+                s_ax[k][tid] = tx_ + cam.vertical[0] * vv;
+                s_ay[k][tid] = ty_ + cam.vertical[1] * vv;
+                s_az[k][tid] = tz_ + cam.vertical[2] * vv;
+                s_rs[k][tid] = rs;
+                nd0 = 2;
+            }
+        }
+        s_nd[k][tid] = nd0;
+    }
+    // ---- B: the rejection walk down the lane's column (only this lane touches its column: no barrier needed)
+    {
+        int k = 0;
+        while (k < PT_RG_ROWS && s_nd[k][tid] == 0xffffffffu) k++;
+        uint64_t rs = k < PT_RG_ROWS ? s_rs[k][tid] : 0;
+        uint32_t nd = 2;
+        while (k < PT_RG_ROWS) {
+            const double d0 = ptm::stream_next(rs), d1 = ptm::stream_next(rs), d2 = ptm::stream_next(rs);
+            nd += 3;
+            const double rx = d0 * 2 - 1, ry = d1 * 2 - 1, rz = d2 * 2 - 1;
+            const double lenSq = rx * rx + ry * ry + rz * rz;
+            if (!(lenSq >= 1.0)) {  // accepted (randomInUnitSphere keeps drawing while lenSq >= 1)
+                s_rx[k][tid] = rx;
+                s_ry[k][tid] = ry;
+                s_rs[k][tid] = rs;
+                s_nd[k][tid] = nd;
+                k++;
+                while (k < PT_RG_ROWS && s_nd[k][tid] == 0xffffffffu) k++;
+                if (k < PT_RG_ROWS) rs = s_rs[k][tid];
+                nd = 2;
+            }
+        }
+    }
+    // ---- C: lens offset, ray, coalesced stores
+    const size_t nj = F.njobs;
+#pragma unroll
+    for (int k = 0; k < PT_RG_ROWS; k++) {
+        const uint32_t myjob = (row0 + (uint32_t)k) * 64u + lane;
+        if (myjob >= F.njobs) continue;
+        const uint32_t nd = s_nd[k][tid];
+        if (nd == 0xffffffffu) {
+            ray_ndraw[myjob] = 0xffffu;
+            continue;
+        }
+        const double rx = s_rx[k][tid] * cam.lens_radius;
+        const double ry = s_ry[k][tid] * cam.lens_radius;
+        const double offx = cam.u[0] * rx + cam.v[0] * ry;
+        const double offy = cam.u[1] * rx + cam.v[1] * ry;
+        const double offz = cam.u[2] * rx + cam.v[2] * ry;
+        ray[myjob] = cam.origin[0] + offx;
+        ray[nj + myjob] = cam.origin[1] + offy;
+        ray[2 * nj + myjob] = cam.origin[2] + offz;
+        ray[3 * nj + myjob] = (s_ax[k][tid] - cam.origin[0]) - offx;
+        ray[4 * nj + myjob] = (s_ay[k][tid] - cam.origin[1]) - offy;
+        ray[5 * nj + myjob] = (s_az[k][tid] - cam.origin[2]) - offz;
+        ray_rng[myjob] = s_rs[k][tid];
+        ray_ndraw[myjob] = (uint16_t)(nd < 0xfffeu ? nd : 0xfffeu);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Shading pieces shared by trace_kernel (all-in-one form) and glass_kernel.  Every expression is the reference's,
 // in the reference's association order.

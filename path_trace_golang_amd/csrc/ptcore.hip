@@ -838,8 +838,12 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
         if (int32_t rc = dev_events(d, d.ev_raygen, d.n_raygen + 1)) return rc;
         EventPair &eg = d.ev_raygen[d.n_raygen++];
         HIP_TRY(hipEventRecord(eg.a, d.stream));
-        hipLaunchKernelGGL(ptk::raygen_kernel, dim3((F.njobs + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, d.stream, F, fr.cam,
-                           d.ray.p, d.ray_rng.p, d.ray_ndraw.p);
+        if (fr.cam.lens_radius > 0 && !std::getenv("PTCORE_RAYGEN_SIMPLE"))  // thin lens: the rejection loop, PT_RG_ROWS jobs per lane
+            hipLaunchKernelGGL(ptk::raygen_lens_kernel, dim3((F.njobs + PT_BLOCK * PT_RG_ROWS - 1) / (PT_BLOCK * PT_RG_ROWS)), dim3(PT_BLOCK), 0,
+                               d.stream, F, fr.cam, d.ray.p, d.ray_rng.p, d.ray_ndraw.p);
+        else
+            hipLaunchKernelGGL(ptk::raygen_kernel, dim3((F.njobs + PT_BLOCK - 1) / PT_BLOCK), dim3(PT_BLOCK), 0, d.stream, F, fr.cam,
+                               d.ray.p, d.ray_rng.p, d.ray_ndraw.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(eg.b, d.stream));
         if (fr.wavefront) {
