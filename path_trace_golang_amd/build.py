@@ -69,8 +69,19 @@ def build_host(force: bool = False) -> list[str]:
     return [lib, exe]
 
 
+def build_tools(force: bool = False) -> list[str]:
+    """Stand-alone gfx950 measurement programs under tools/ (not part of the library)."""
+    src = os.path.join(ROOT, "tools", "valu_floor.hip")
+    out = os.path.join(ROOT, "tools", "valu_floor")
+    if not os.path.exists(src):
+        return []
+    if force or _newer(out, [src]):
+        _run([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", src, "-o", out])
+    return [out]
+
+
 def build_all(force: bool = False) -> list[str]:
-    return [build_core(force), *build_host(force)]
+    return [build_core(force), *build_host(force), *build_tools(force)]
 
 
 if __name__ == "__main__":

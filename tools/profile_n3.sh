@@ -1,8 +1,8 @@
 #!/bin/bash
 # rocprofv3 passes for the BVH path on a synthetic scene (run on the GPU box through gpurun).
-#   tools/profile_n3.sh <tag> [objects]
+#   tools/profile_n3.sh <tag> [objects] [mega|wavefront]
 set -o pipefail
-TAG=${1:-r01_n3}; N=${2:-100000}
+TAG=${1:-r02_n3}; N=${2:-100000}; export PTCORE_PIPELINE=${3:-mega}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -15,7 +15,7 @@ for PMC in \
   "FETCH_SIZE" \
   "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" ; do
-  rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 tools/probe_synth.py $N > $OUT/pmc$i.txt 2> $OUT/pmc$i.err || { echo "pmc pass $i failed"; tail -3 $OUT/pmc$i.err; }
+  rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -- python3 tools/probe_synth.py $N > $OUT/pmc$i.txt 2> $OUT/pmc$i.err || { echo "pmc pass $i failed"; tail -3 $OUT/pmc$i.err; exit 1; }
   echo "pmc pass $i done"
   i=$((i+1))
 done
