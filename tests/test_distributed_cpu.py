@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, into_views=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -45,8 +45,18 @@ def _worker(rank, world, port, out_path):
     def untile(bufs, stride_tiles):
         return tiling.untile([b.numpy() for b in bufs], W, H, world, 4, np.uint8, stride_tiles)
 
-    out = distributed.assemble_frame(tiles, W, H, rank, world, untile)
+    scratch = None
+    packed = None
+    if into_views and rank == 0:
+        # what bench.py does: the receive list is views of one contiguous buffer, so the gather needs no copy before the untile
+        packed = torch.empty(world * tiles.numel(), dtype=torch.uint8)
+        scratch = list(packed.split(tiles.numel()))
+    out = distributed.assemble_frame(tiles, W, H, rank, world, untile, scratch)
     if rank == 0:
+        if into_views:  # the shards really landed back to back in `packed`
+            flat = np.concatenate([b.numpy() for b in scratch])
+            assert np.array_equal(flat, packed.numpy())
+            assert scratch[1].data_ptr() == packed.data_ptr() + tiles.numel()
         np.save(out_path, out)
     dist.barrier()
     dist.destroy_process_group()
@@ -59,6 +69,18 @@ def test_two_rank_gloo_gather_matches_single_rank(tmp_path, oracle):
     out = str(tmp_path / "frame.npy")
     port = _free_port()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    ref = oracle.render(oracle.Scene.load(scene_path("example_simple")), W, H, SPP, DEPTH, seed=SEED, want=("rgba",))
+    assert np.array_equal(got, ref["rgba"])
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gather_into_views_of_one_buffer(tmp_path, oracle):
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "frame.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out, True), nprocs=2, join=True)
     got = np.load(out)
     ref = oracle.render(oracle.Scene.load(scene_path("example_simple")), W, H, SPP, DEPTH, seed=SEED, want=("rgba",))
     assert np.array_equal(got, ref["rgba"])
