@@ -22,8 +22,15 @@
 //                                   runs on the objects whose own box is pierced; nodes and objects
 //                                   are read from HBM/L2 (top of the tree from LDS), the stack is in LDS.
 //                     SCAN_VERIFY*  run a culled strategy AND the plain scan, count disagreements.
-//   raygen_kernel   one thread per job: stream init, pixel jitter and camera.getRay
-//                   (camera.go:60-74, renderer.go:181-184) as a coherent pre-pass of every chunk.
+//                   Split form (SPLIT): a dielectric hit is not shaded in the loop; the path is parked in a path-state
+//                   queue in HBM and comes back through a continuation queue (see glass_kernel); the scan is then
+//                   compiled for closest hits only.
+//   glass_kernel    the dielectric bounce of every parked path, all lanes on the same branch: scatter
+//                   (materials.go:162-200), exit search over the dielectric objects only (renderer.go:316-349), its
+//                   epilogue (renderer.go:352-370), roulette (renderer.go:375-403); survivors -> continuation queue.
+//   raygen_kernel / raygen_lens_kernel   one thread per job: stream init, pixel jitter and camera.getRay
+//                   (camera.go:60-74, renderer.go:181-184) as a coherent pre-pass of every chunk; with a thin lens a
+//                   lane walks a column of four jobs so that a wave does not wait for its unluckiest rejection loop.
 //   resolve_kernel  per pixel slot, adds the chunk's sample radiances IN SAMPLE ORDER
 //                   to the running sum (renderer.go:186), and on request finishes the
 //                   pixel: 1/spp, sqrt gamma, *255.999, clamp, truncate (renderer.go:190-221).
