@@ -1348,17 +1348,6 @@ __device__ __forceinline__ P pt_launder(P p) {
     return p;
 }
 
-// Appends the lanes with `push` set to a path queue: one atomic per wave, consecutive slots in lane order.
-// Returns this lane's slot.  The queues hold one entry per job of the chunk at most, so they cannot overflow.
-__device__ __forceinline__ uint32_t queue_reserve(uint32_t *count, bool push, uint32_t lane) {
-    const uint64_t pm = __ballot(push);
-    const uint32_t leader = (uint32_t)__ffsll((long long)pm) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(pm));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-    return base + lane_rank(pm);
-}
-
 // SPLIT: dielectric hits are not shaded here.  The lane parks the path in the glass queue (HBM) and takes the next
 // job; glass_kernel handles them together, and the paths that go on come back through the continuation queue.
 // The trace loop then never runs the dielectric branch, the exit search or its epilogue at 14 % of its lanes,

@@ -311,3 +311,21 @@ def test_scene_settings_override_follows_the_editor_rule(host, tmp_path):
     host.pth_settings_for_scene(h, b"final", out)
     assert tuple(out) == (64, 36, 4000, 10)
     host.pth_scene_free(h)
+
+
+def test_bench_refuses_a_world_size_that_does_not_match_gpus():
+    """bench.py --gpus N must be started with exactly N ranks: any mismatch is an error, before any GPU work."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "--nproc-per-node 2" in r.stderr
