@@ -772,7 +772,7 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
             const bool want = cur >= 0 && pend == 0;
             const uint64_t wm = __ballot(want);
             if (wm == 0 || leaving) break;
-            if (__popcll(wm) < F.bvh_node_min && __ballot(pend != 0) != 0) break;
+            if ((int)__popcll(wm) < F.bvh_node_min && __ballot(pend != 0) != 0) break;
             if (want) {
             if (PROF) ph.lanes[SEC_NBOX]++;  // node visits (lane count)
             BvhNode nd;
