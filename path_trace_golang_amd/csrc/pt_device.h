@@ -138,6 +138,7 @@ struct DevFrame {
     int32_t bvh_min_lanes;            // a traversal loop with fewer lanes still walking leaves them for the next trip
     int32_t bvh_node_min;             // the node walk yields to the exact tests of waiting lanes below this many walking lanes
     int32_t bvh_leaf_single;          // 1: one exact test per waiting lane and pass, then back to the walk
+    int32_t planes_y;                 // 1: every plane has the normal (0, 1, 0) (all the engine ever builds): plane_exact_y applies
     uint32_t debug_drop;              // verify instantiations only (PTCORE_DEBUG_DROP): candidate bits cleared on purpose, so that
                                       // the disagreement counter can be shown to move
     int32_t broad_ok;    // 1: at most 32 sphere records and 32 box records -> candidate-bitmask scan usable;

@@ -140,6 +140,21 @@ struct RayD {
     double ox, oy, oz, dx, dy, dz;
 };
 
+// math.Max / math.Min (materials.go:185, math.go:49, renderer.go:378,384) as ONE v_max_f64 / v_min_f64 plus the NaN rule.
+// The instruction already does what Go's special cases ask for -- an infinity wins, max(+0, -0) = +0, min(+0, -0) = -0
+// (CDNA ISA, V_MAX_F64 / V_MIN_F64) -- except for a NaN operand, which it drops and Go propagates (unless the other one is
+// the winning infinity).  ptm::go_max / go_min spell the special cases out (15 instructions each); compared bit for bit by
+// pt_debug_div_selftest, whose first run found the infinity-before-NaN order.
+__device__ __forceinline__ double dev_go_max(double x, double y) {
+    const double m = __builtin_fmax(x, y);
+    // Go tests for +Inf before it tests for NaN: Max(+Inf, NaN) = +Inf -- which is what the instruction, dropping the NaN, returned
+    return ((x != x || y != y) && !(m == ptm::inf_pos())) ? ptm::qnan() : m;
+}
+__device__ __forceinline__ double dev_go_min(double x, double y) {
+    const double m = __builtin_fmin(x, y);
+    return ((x != x || y != y) && !(m == -ptm::inf_pos())) ? ptm::qnan() : m;
+}
+
 // IEEE division n / d with the reciprocal work shared between several numerators.  The compiler's f64 division is
 //   ds = div_scale(d), ns = div_scale(n); y = rcp(ds) refined by two Newton steps; q0 = ns*y; r = fma(-ds, q0, ns);
 //   q = div_fmas(r, y, q0); div_fixup(q, d, n)
@@ -264,6 +279,17 @@ __device__ __forceinline__ bool plane_exact(double px, double py, double pz, dou
     const double denom = nx * r.dx + ny * r.dy + nz * r.dz;
     if (ptm::f_abs(denom) < 1e-6) return false;
     t = ((px - r.ox) * nx + (py - r.oy) * ny + (pz - r.oz) * nz) / denom;
+    return !(t < tmin || t > tmax);
+}
+
+// The same for the only planes the engine builds, normal (0, 1, 0) (objects.go:252), and a ray with finite components
+// (the culled scans' `tame` rays): n.d = (0*dx + 1*dy) + 0*dz is dy itself unless dy is a zero, which the 1e-6 test rejects
+// whatever its sign, and the numerator is (py - oy) itself unless that is a zero, whose quotient falls below tMin whatever
+// its sign.  Same decisions, same t, ten FP64 operations fewer per plane and scan.
+__device__ __forceinline__ bool plane_exact_y(double py, const RayD &r, double tmin, double tmax, double &t) {
+    const double denom = r.dy;
+    if (ptm::f_abs(denom) < 1e-6) return false;
+    t = (py - r.oy) / denom;
     return !(t < tmin || t > tmax);
 }
 
@@ -423,7 +449,8 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         const auto &o = g_obj[i];
         if (MODE == 1 && !(o.kind & 0x100)) continue;  // wave-uniform
         double t = 0;
-        bool acc = plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t);
+        bool acc = F.planes_y ? plane_exact_y(o.a[1], r, tmin, tmax, t)
+                              : plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t);
         if (MODE < 0 && mode != 0 && !(o.kind & 0x100)) acc = false;
         if (acc) {
             if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
@@ -553,7 +580,8 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
         const auto &o = g_obj[i];
         if (mode != 0 && !(o.kind & 0x100)) continue;
         double t = 0;
-        if (plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t)) {
+        if (F.planes_y ? plane_exact_y(o.a[1], r, tmin, tmax, t)
+                       : plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t)) {
             if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
                           : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_PLANE, r, t))) {
                 best = i;
@@ -705,7 +733,8 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
         const auto &o = g_obj[i];
         if (mode != 0 && !(o.kind & 0x100)) continue;
         double t = 0;
-        if (plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t)) {
+        if (F.planes_y ? plane_exact_y(o.a[1], r, tmin, tmax, t)
+                       : plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t)) {
             if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
                           : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(o, KIND_PLANE, r, t))) {
                 best = i;
@@ -1143,7 +1172,7 @@ __device__ __forceinline__ void dielectric_scatter(const DevMat &m, bool ff, dou
                                                    uint32_t &j_draw, double &ndx, double &ndy, double &ndz) {
     ndx = rfx; ndy = rfy; ndz = rfz;
     const double ratio = ff ? m.inv_ior : m.ior;
-    const double cosTheta = ptm::go_min(-(ux * nx + uy * ny + uz * nz), 1.0);
+    const double cosTheta = dev_go_min(-(ux * nx + uy * ny + uz * nz), 1.0);
     const double sinTheta = ptm::f_sqrt(1.0 - cosTheta * cosTheta);
     const bool cannot = ratio * sinTheta > 1.0;
     const double r0 = ff ? m.r0_front : m.r0_back;
@@ -1154,7 +1183,7 @@ __device__ __forceinline__ void dielectric_scatter(const DevMat &m, bool ff, dou
         reflects = reflectProb > xi;
     }
     if (!reflects) {  // refractVec, math.go:48-64
-        const double ct = ptm::go_min(-ux * nx - uy * ny - uz * nz, 1.0);
+        const double ct = dev_go_min(-ux * nx - uy * ny - uz * nz, 1.0);
         double qx = ux + nx * ct, qy = uy + ny * ct, qz = uz + nz * ct;
         qx *= ratio; qy *= ratio; qz *= ratio;
         const double perpLenSq = qx * qx + qy * qy + qz * qz;
@@ -1187,11 +1216,11 @@ __device__ __forceinline__ bool roulette_advance(int &depth, double attx, double
                                                  uint64_t &rs, uint32_t &c_draw, uint32_t &j_draw) {
     bool finished = false;
     if (depth <= 3) {  // renderer.go:375-393
-        const double maxAtt = ptm::go_max(attx, ptm::go_max(atty, attz));
+        const double maxAtt = dev_go_max(attx, dev_go_max(atty, attz));
         if (maxAtt < 1e-6) {
             finished = true;
         } else {
-            const double rrProb = ptm::go_min(maxAtt, 0.95);
+            const double rrProb = dev_go_min(maxAtt, 0.95);
             const double xi = draw_next<STATS>(rs, c_draw, j_draw);
             if (xi > rrProb) {
                 finished = true;
@@ -2115,6 +2144,17 @@ __global__ __launch_bounds__(PT_BLOCK) void div_selftest_kernel(unsigned long lo
         const double q1 = div_shared(n, d, div_recip(d));
         const bool same = ptm::to_bits(q0) == ptm::to_bits(q1) || (q0 != q0 && q1 != q1);
         bad += same ? 0u : 1u;
+        // math.Max / math.Min: the one-instruction forms against the spelled-out ones, on the same operands and on the
+        // special values (zeros of both signs, infinities, NaN, 1, denormals) in every combination over the run
+        const uint64_t sp[8] = {0x0ULL, 0x8000000000000000ULL, 0x7ff0000000000000ULL, 0xfff0000000000000ULL,
+                                0x7ff8000000000001ULL, 0x3ff0000000000000ULL, 0x0000000000000001ULL, 0x800fffffffffffffULL};
+        double mx = n, my = d;
+        if (((h0 >> 3) & 3u) == 0) mx = ptm::from_bits(sp[(h0 >> 5) & 7u]);
+        if (((h1 >> 3) & 3u) == 0) my = ptm::from_bits(sp[(h1 >> 5) & 7u]);
+        const double a0 = ptm::go_max(mx, my), a1 = dev_go_max(mx, my), b0 = ptm::go_min(mx, my), b1 = dev_go_min(mx, my);
+        const bool same_mm = (ptm::to_bits(a0) == ptm::to_bits(a1) || (a0 != a0 && a1 != a1)) &&
+                             (ptm::to_bits(b0) == ptm::to_bits(b1) || (b0 != b0 && b1 != b1));
+        bad += same_mm ? 0u : 1u;
     }
     const uint32_t w = wave_sum(bad);
     if ((threadIdx.x & (PT_WAVE - 1)) == 0 && w) atomicAdd(out, (unsigned long long)w);

@@ -429,6 +429,11 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     F.n_bsph = (int32_t)fr.bsph.size();
     F.n_bbox = (int32_t)fr.bbox.size();
     F.n_plane = (int32_t)fr.plane_idx.size();
+    F.planes_y = 1;
+    for (int32_t i : fr.plane_idx) {
+        const DevObj &o = world[(size_t)i];
+        if (!(o.b[0] == 0.0 && o.b[1] == 1.0 && o.b[2] == 0.0) || std::signbit(o.b[0]) || std::signbit(o.b[2])) F.planes_y = 0;
+    }
     F.n_dsph = (int32_t)fr.bsph_diel.size();
     F.n_dbox = (int32_t)fr.bbox_diel.size();
     F.broad_ok = (fr.bsph.size() <= 32 && fr.bbox.size() <= 32) ? 1 : (fr.bsph.size() <= 128 && fr.bbox.size() <= 128) ? 2 : 0;
