@@ -22,7 +22,7 @@ def klass(name: str):
     m = re.search(r"trace_kernel<(\w+), (\w+), (\d+), (\w+)>", name)
     if m:
         return "trace_split" if m.group(4) == "true" else "trace_allinone"
-    for k in ("glass_kernel", "raygen_kernel", "resolve_kernel", "wf_", "untile_kernel"):
+    for k in ("glass_kernel", "raygen_lens_kernel", "raygen_kernel", "resolve_kernel", "wf_", "untile_kernel"):
         if k in name:
             return k.replace("_kernel", "")
     return None
