@@ -15,7 +15,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libptcore.so")
+LIB_PATH = os.environ.get("PTCORE_LIB") or os.path.join(PKG, "libptcore.so")  # PTCORE_LIB: another build of the same ABI (A/B runs)
 
 PT_ABI_VERSION = 2
 PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NOMEM, PT_ERR_STATE = range(6)

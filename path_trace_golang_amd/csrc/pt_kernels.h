@@ -55,6 +55,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the p
 #define PT_BLOCK 256
 #define PT_QUEUE_BLOCK 256u     // glass-queue slots a wave of trace_kernel reserves per atomic
 #define PT_CONT_BLOCK 1024u     // continuation slots a wave of glass_kernel reserves per atomic
+#ifndef PT_BVH_WAVES
+#define PT_BVH_WAVES 4  // blocks of 256 threads per CU (= waves per SIMD) the BVH kernels are compiled for
+#endif
 #define PT_HOLE 0xffffffffu     // job id of a reserved but unused queue slot
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
@@ -803,6 +806,7 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
             if (wm == 0 || leaving) break;
             if ((int)__popcll(wm) < F.bvh_node_min && __ballot(pend != 0) != 0) break;
             if (want) {
+            PH_BEGIN(SEC_COSINE)  // BVH runs: wave-level executions, lanes and cycles of the node visit
             if (PROF) ph.lanes[SEC_NBOX]++;  // node visits (lane count)
             BvhNode nd;
             if (cur < F.bvh_lds_nodes) nd = lds_nodes[cur];  // top of the tree: LDS packet
@@ -894,6 +898,7 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 pend_meta = meta;
                 pend_base = nd.obj_base;
             }
+            PH_END(SEC_COSINE)
             }
         }
         // ---- exact tests of the objects gathered at the last node
@@ -901,6 +906,8 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
             PH_BEGIN(SEC_NSPH)
             if (PROF) n_leaf++;
             do {
+                PH_BEGIN(SEC_UNITDIR)  // BVH runs: wave-level executions and lanes of one exact test (cycles: up to the test itself)
+                PH_END(SEC_UNITDIR)
                 const uint32_t s = (uint32_t)__builtin_ctz(pend);
                 pend &= pend - 1;
                 const BvhObj &bo = bobjs[pend_base + (int)((pend_meta >> (2u * s)) & 3u)];
@@ -1383,7 +1390,7 @@ __device__ __forceinline__ P pt_launder(P p) {
 // and no lane spends a whole trip through the scan on an exit search.
 // (launch bounds: the flat scans are asked to fit five waves per SIMD = 96 VGPRs, the BVH forms four = 128; the diagnostic form is not held to anything)
 template <bool STATS, bool PROF, int SCAN, bool SPLIT>
-__global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? 4 : 5) void trace_kernel(const TraceArgs A) {
+__global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? PT_BVH_WAVES : 5) void trace_kernel(const TraceArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevFrame &F = A.F;
     const TraceBuffers &B = A.B;  // set-up and epilogue only; the loop reads the argument block through KA

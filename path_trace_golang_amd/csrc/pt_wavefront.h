@@ -225,7 +225,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_init_kernel(const WfArgs A) {
 // Persistent waves; a lane that has its answer takes the next entry at once, so the walk loop of scan_bvh always
 // starts on a full wave (it is left, as in trace_kernel, once fewer than F.bvh_min_lanes lanes are still walking).
 template <int MODE, bool VERIFY>
-__global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(const WfArgs A) {
+__global__ __launch_bounds__(PT_BLOCK, PT_BVH_WAVES) void wf_traverse_kernel(const WfArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevFrame &F = A.F;
     const TraceBuffers &B = A.B;

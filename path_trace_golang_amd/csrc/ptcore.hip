@@ -166,6 +166,7 @@ struct SceneData {
     std::vector<BvhObj> bvh_objs;
     int bvh_depth = 0;
     int bvh_stack_need = 0;
+    bool has_glass = false;           // some object is dielectric
     size_t lds_bytes = 0;
     size_t glass_lds_bytes = 0;
     int scan = 0;
@@ -1135,15 +1136,25 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     if (const char *e = std::getenv("PTCORE_BVH_LEAF_SINGLE")) F.bvh_leaf_single = std::atoi(e) != 0;
     F.bvh_node_min = 16;
     if (const char *e = std::getenv("PTCORE_BVH_NODE_MIN")) F.bvh_node_min = std::max(0, std::min(65, std::atoi(e)));
-    if (big && F.bvh_root == 0 && stack_bytes < 40960)
-        F.bvh_lds_nodes = (int32_t)std::min<size_t>((40960 - stack_bytes) / sizeof(BvhNode), (size_t)F.bvh_main_nodes);
+    size_t lds_budget = (size_t)(160 * 1024 / PT_BVH_WAVES);
+    if (const char *e = std::getenv("PTCORE_BVH_LDS_BUDGET")) lds_budget = (size_t)std::max(0, std::min(160 * 1024, std::atoi(e)));
+    if (big && F.bvh_root == 0 && stack_bytes < lds_budget)
+        F.bvh_lds_nodes = (int32_t)std::min<size_t>((lds_budget - stack_bytes) / sizeof(BvhNode), (size_t)F.bvh_main_nodes);
     sd.lds_bytes = big ? stack_bytes + (size_t)F.bvh_lds_nodes * sizeof(BvhNode)
                        : (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
                              (size_t)(sd.bsph.size() + sd.bbox.size()) * sizeof(int);
     sd.glass_lds_bytes = (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
                          (size_t)(sd.bsph_diel.size() + sd.bbox_diel.size()) * sizeof(int);
+    // PTCORE_BVH_LDS_PAD=<bytes>: unused LDS on top of the BVH plan (occupancy experiments: 4 blocks per CU fit 40 KiB each)
+    if (const char *e = std::getenv("PTCORE_BVH_LDS_PAD"))
+        if (big) sd.lds_bytes += (size_t)std::max(0, std::min(120 * 1024, std::atoi(e)));
+    if (big && std::getenv("PTCORE_VERBOSE"))
+        std::fprintf(stderr, "ptcore: BVH %d nodes (%d wide levels), %d objects, stack %d entries per lane, %d nodes in LDS, %zu B of LDS per block\n",
+                     F.n_bvh_nodes, sd.bvh_depth, F.n_bvh_objs, F.bvh_stack, F.bvh_lds_nodes, sd.lds_bytes);
     if (sd.lds_bytes > 160 * 1024)
         return fail(PT_ERR_INVALID, "scene does not fit the 160 KiB LDS of a CU with this scan strategy (use the BVH: unset PTCORE_SCAN)");
+    sd.has_glass = false;
+    for (const DevObj &o : sd.world) sd.has_glass = sd.has_glass || (o.kind & 0x100);
     sd.gen++;
     sd.valid = true;
     return PT_OK;
@@ -1160,8 +1171,7 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     fr.scan = sd.scan;
     fr.lds_bytes = sd.lds_bytes;
     fr.glass_lds_bytes = sd.glass_lds_bytes;
-    fr.has_glass = false;
-    for (const DevObj &o : sd.world) fr.has_glass = fr.has_glass || (o.kind & 0x100);
+    fr.has_glass = sd.has_glass;
     // split passes: the bitmask scan of reference-sized scenes; a path has at most max_depth dielectric bounces
     fr.split_rounds = 0;
     if ((sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY || sd.scan == ptk::SCAN_BROAD_WIDE || sd.scan == ptk::SCAN_VERIFY_WIDE) &&
@@ -1668,11 +1678,21 @@ int32_t pt_render(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uint
     if (!ctx) return fail(PT_ERR_INVALID, "ctx is null");
     if ((nseg || ndraw) && cfg && !(cfg->flags & PT_FLAG_PIXEL_STATS))
         return fail(PT_ERR_INVALID, "nseg/ndraw need PT_FLAG_PIXEL_STATS");
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
     if (int32_t rc = pt_begin(ctx, scene, cfg)) return rc;
+    const auto t1 = clk::now();
     int32_t rc = pt_step(ctx, cfg->samples_per_px, nullptr);
+    const auto t2 = clk::now();
     if (rc == PT_OK) rc = read_frame(ctx, rgba, stride, accum, nseg, ndraw);
+    const auto t3 = clk::now();
     pt_stats st;
     int32_t rc2 = pt_end(ctx, &st);
+    if (std::getenv("PTCORE_VERBOSE")) {
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "ptcore: pt_render host phases: begin %.2f ms, step %.2f ms, read %.2f ms, end %.2f ms\n", ms(t0, t1), ms(t1, t2),
+                     ms(t2, t3), ms(t3, clk::now()));
+    }
     if (stats) *stats = st;
     return rc != PT_OK ? rc : rc2;
 }

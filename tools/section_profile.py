@@ -10,8 +10,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "gpu_showcase"
 w, h, spp, d = (int(x) for x in (sys.argv[2:6] if len(sys.argv) >= 6 else (1920, 1080, 42, 8)))
 # "shade": hit record + emitted + scatter of every material kind in one section since round 2 (shade_hit); cosine, diel and
 # unitdir are no longer timed apart; diel / exitpost only run in the all-in-one form (PTCORE_SPLIT_ROUNDS=0)
-SEC = ["iter", "raygen", "hist0", "scan", "hist1", "hist2", "shade", "(cosine)", "(diel)", "exitpost", "rr",
-       "finish", "sky", "(unitdir)", "broad", "nar_sph", "nar_box", "plane"]
+SEC = ["iter", "raygen", "hist0", "scan", "hist1", "hist2", "shade", "cos|node", "(diel)", "exitpost", "rr",
+       "finish", "sky", "udir|test", "broad", "nar_sph", "nar_box", "plane"]
 ctx = capi.Context(ndev=1)
 if name.startswith("synth:"):
     from path_trace_golang_amd import synth
