@@ -807,7 +807,11 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
             if ((int)__popcll(wm) < F.bvh_node_min && __ballot(pend != 0) != 0) break;
             if (want) {
             PH_BEGIN(SEC_COSINE)  // BVH runs: wave-level executions, lanes and cycles of the node visit
-            if (PROF) ph.lanes[SEC_NBOX]++;  // node visits (lane count)
+            if (PROF) {
+                ph.lanes[SEC_NBOX]++;  // node visits (lane count)
+                if (cur < F.bvh_lds_nodes) ph.exec[SEC_DIEL]++;       // ... served by the LDS copy of the top of the tree
+                if (cur < 4 * F.bvh_lds_nodes) ph.lanes[SEC_DIEL]++;  // ... that a four times larger copy would serve
+            }
             BvhNode nd;
             if (cur < F.bvh_lds_nodes) nd = lds_nodes[cur];  // top of the tree: LDS packet
             else nd = nodes[cur];                            // below: HBM / L2

@@ -33,6 +33,8 @@ if name.startswith("synth:"):
     g = lambda i, k: buf[3 * SEC.index(i) + k]
     print("object batches per closest-hit scan: <4: %d  <16: %d  <64: %d  <256: %d  <1024: %d  >=1024: %d" % (
         g("hist0", 0), g("hist0", 2), g("hist1", 0), g("hist1", 2), g("hist2", 0), g("hist2", 2)))
+    print("node visits (lanes): %d, of them in the LDS copy of the top of the tree: %d, in a copy four times as large: %d" % (
+        g("nar_box", 1), g("(diel)", 0), g("(diel)", 1)))
     print("exit searches (even bins only): <4: %d  [16,64): %d  [256,1024): %d" % (g("hist0", 1), g("hist1", 1), g("hist2", 1)))
 
 os.environ["PTCORE_VERBOSE"] = "1"
