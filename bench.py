@@ -103,7 +103,10 @@ def main() -> int:
         else:
             dist.init_process_group(backend)
 
-    capi.load()
+    # Steady-state rendering (frame after frame on one context, what this bench times): job buffers of 160 GiB, so that a
+    # 1080p x 1024 spp frame takes 4 passes instead of 13 (each pass ends in the ragged tail of five persistent kernels,
+    # ~1.7 ms).  The library's own default stays 48 GiB because a one-shot render pays ~6 ms of hipMalloc per GiB.
+    os.environ.setdefault("PTCORE_L_BUDGET_MB", "163840")
     L = capi.load()
     ctx = capi.Context(devices=[dev_index])
     sc = scene.load(os.path.join(ROOT, "scenes", args.scene + ".json"))
@@ -256,7 +259,7 @@ def main() -> int:
             "config": {"workload": "scenes/%s.json %dx%d, %d spp, max depth %d, seed %d (BASELINE config 4)"
                                    % (args.scene, W, H, args.spp, args.depth, args.seed),
                        "tiles": "32x32 interleaved over %d rank(s)" % world, "gather": ("rccl" if backend == "nccl" else backend + " (rehearsal)") if world > 1 else "none",
-                       "spp_chunk": chunk},
+                       "spp_chunk": chunk, "job_buffer_budget_mib": int(os.environ["PTCORE_L_BUDGET_MB"])},
             "per_rank_render_ms_per_step": busy_ms,
             "gather_untile_host_ms_per_step": elapsed / steps * 1e3 - max(busy_ms),
             "primary_msamples_per_s": samples / elapsed / 1e6,
