@@ -1,5 +1,8 @@
 #!/bin/bash
-# occupancy experiment on the BVH path: builds of the BVH kernels for 4, 5 and 6 blocks per CU (build_ab/, -DPT_BVH_WAVES=n)
+# occupancy experiment on the BVH path: builds of the BVH kernels for 4, 5 and 6 blocks per CU.  Build the variants first (in the
+# container, they travel with the snapshot):
+#   mkdir -p build_ab && for w in 5 6; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC \
+#     -DPT_BVH_WAVES=$w -Iinclude -shared path_trace_golang_amd/csrc/ptcore.hip -o build_ab/libptcore_w$w.so; done
 OUT=gpurun_out/occ_probe.txt; : > $OUT
 for pipe in mega wavefront; do
 for w in 4 5 6; do
