@@ -91,7 +91,7 @@ struct Builder {
     std::vector<BinNode> bin;
     double margin;
 
-    // chooses the split position inside [a, b): binned SAH (16 bins) over each centroid axis, the cheapest of the
+    // chooses the split position inside [a, b): binned SAH (32 bins: 5 % fewer node visits per ray than 16 on the synthetic scenes, tools/bvh_quality.cpp) over each centroid axis, the cheapest of the
     // three wins; median of the widest axis when no bin boundary separates the objects
     int split(int a, int b) {
         Aabb cb;
@@ -110,7 +110,7 @@ struct Builder {
         }
         const int mid = (a + b) / 2;
         if (!(ext > 0)) return mid;  // all centroids coincide (or are not finite): any split is as good
-        constexpr int NB = 16;
+        constexpr int NB = 32;
         double best = INFINITY;
         int best_bin = -1, best_axis = -1;
         double best_scale = 0;

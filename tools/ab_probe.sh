@@ -1,10 +1,9 @@
 #!/bin/bash
-# same-box A/B of two builds of libptcore.so on the BVH probe: tools/ab_probe.sh <libA> <libB> [objects ...]
-A=$1; B=$2; shift 2
+# same-box A/B of builds of libptcore.so on the BVH probe: OBJS="10000 100000" tools/ab_probe.sh <libA> <libB> [<libC> ...]
 OUT=gpurun_out/ab_probe.txt; : > $OUT
 for rep in 1 2; do
-for lib in $A $B; do
+for lib in "$@"; do
   echo "== $lib (run $rep)" >> $OUT
-  PTCORE_LIB=$PWD/$lib timeout -k 10 200 python tools/probe_synth.py ${@:-100000} 2>&1 | grep -v amdgpu.ids >> $OUT || exit 1
+  PTCORE_LIB=$PWD/$lib timeout -k 10 200 python tools/probe_synth.py ${OBJS:-100000} 2>&1 | grep -v amdgpu.ids | sed -E 's/gen .* spp 16: //' >> $OUT || exit 1
 done
 done
