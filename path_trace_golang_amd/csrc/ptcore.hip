@@ -84,6 +84,7 @@ struct Device {
     DevBuf<BroadSphere> bsph;
     DevBuf<BroadBox> bbox;
     DevBuf<int32_t> plane_idx;
+    size_t jobs_cap = 0;              // jobs per pass this device could hold after an allocation failed (0: never failed)
     DevBuf<BvhNode> bvh_nodes;
     DevBuf<BvhObj> bvh_objs;
     DevBuf<double> L;
@@ -574,6 +575,9 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
     }
     // per-chunk job buffers; when the device cannot give that much right now the chunk is halved until it can
     // (the ordered accumulation makes the pixels independent of the chunk size)
+    // (a device that once could not give the budget keeps the size that fitted: trying the full budget again on every frame
+    // costs seconds of hipMalloc / hipFree per frame when two processes share one GPU)
+    if (d.jobs_cap && (size_t)ns * fr.chunk > d.jobs_cap) fr.chunk = (uint32_t)std::max<size_t>(1, d.jobs_cap / ns);
     for (;;) {
         const size_t njobs_max = (size_t)ns * fr.chunk;
         hipError_t e = d.L.reserve(4 * njobs_max);
@@ -611,6 +615,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         d.gq_d.release(); d.cq_d.release(); d.gq_rs.release(); d.cq_rs.release(); d.gq_u32.release(); d.cq_u32.release();
         d.xq_d.release(); d.xq_rs.release(); d.xq_u32.release();
         fr.chunk = std::max<uint32_t>(1, fr.chunk / 2);
+        d.jobs_cap = (size_t)ns * fr.chunk;
         if (std::getenv("PTCORE_VERBOSE")) std::fprintf(stderr, "ptcore: device %d is short of memory, samples per pass reduced to %u\n", d.ordinal, fr.chunk);
     }
     if (!d.ev_first) {
