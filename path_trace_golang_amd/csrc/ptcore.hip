@@ -192,7 +192,7 @@ struct pt_ctx {
     int wf_min_lanes = 40; // PTCORE_WF_MIN_LANES: the walk loop of a traversal pass is left for a refill below this many walking lanes
     int wf_sort = 0;       // PTCORE_WF_SORT=1: reorder the paths of a level by direction octant and origin cell
     int split_rounds = 2;  // PTCORE_SPLIT_ROUNDS: trace + glass pass pairs per chunk before the all-in-one pass (bitmask scan only)
-    uint32_t claim = 256;
+    uint32_t claim = 0;   // jobs per queue claim; 0 = by pass shape (dev_step), PTCORE_CLAIM forces one
     int max_blocks_per_cu = 8;
     int scan_mode = -1;  // -1 = choose by scene size; PTCORE_SCAN=uniform|broad|verify|bvh|verify_bvh forces one
     unsigned long long last_mismatches = 0;
@@ -792,7 +792,13 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     F.s0 = s0;
     F.S = S;
     F.njobs = d.nslots * S;
-    F.claim = ctx->claim;
+    // jobs a wave claims per pop of the item cursor: 256, and 512 for the bitmask scans once a pass holds 128 samples per pixel
+    // or more (same-box sweeps, profiles/r02_claim_sweep.txt: C4 at 265 spp per pass 664 / 653 / 654 / 659 / 673 ms for 256 / 512 /
+    // 1024 / 2048 / 4096, at 79 spp per pass 677 / 675 / 678 ms; the BVH path loses 3 % at 512 and 7 % at 1024)
+    {
+        const bool bvh_scan = fr.scan == ptk::SCAN_BVH || fr.scan == ptk::SCAN_VERIFY_BVH;
+        F.claim = ctx->claim ? ctx->claim : (!bvh_scan && S >= 128u) ? 512u : 256u;
+    }
     TraceBuffers B;
     B.objs = d.objs.p;
     B.mats = d.mats.p;
