@@ -62,6 +62,10 @@ struct Stamp {
 #define EIGHT_CMP_U(ins, tail) \
     ins " s[40:41], %8" tail "\n" ins " s[42:43], %9" tail "\n" ins " s[44:45], %10" tail "\n" ins " s[46:47], %11" tail "\n" ins " s[48:49], %12" tail "\n" ins " s[50:51], %13" tail "\n" ins " s[52:53], %14" tail "\n" ins " s[54:55], %15" tail "\n"
 
+// partial waves: does the SIMD skip the 16-lane passes that have no active lane?  (s[54:55] keeps the mask; the bodies used here leave it alone)
+#define EXEC_SET(lo, hi) "s_mov_b64 s[54:55], exec\ns_mov_b32 exec_lo, " lo "\ns_mov_b32 exec_hi, " hi "\n"
+#define EXEC_RESTORE "s_mov_b64 exec, s[54:55]\n"
+
 struct OpDesc { const char *name; int per_body; };
 
 // X(id, name, instructions per BODY, asm text of one BODY)
@@ -147,6 +151,14 @@ struct OpDesc { const char *name; int per_body; };
          "s_and_b64 s[40:41], s[40:41], s[42:43]\ns_or_b64 s[44:45], s[44:45], s[46:47]\ns_and_b64 s[48:49], s[48:49], s[50:51]\ns_or_b64 s[52:53], s[52:53], s[54:55]\n")) \
     X(VALU_SALU, "v_mul_f64 + s_add_u32 alternating (cost per PAIR)", 32,                                                     \
       R8("v_mul_f64 %0, %0, %16\ns_add_u32 s40, s40, 1\nv_mul_f64 %1, %1, %16\ns_add_u32 s41, s41, 1\nv_mul_f64 %2, %2, %16\ns_add_u32 s42, s42, 1\nv_mul_f64 %3, %3, %16\ns_add_u32 s43, s43, 1\n")) \
+    X(FMA_F64_LO16, "v_fma_f64, exec = lanes 0-15", 64, EXEC_SET("0xffff", "0") R8(EIGHT_D("v_fma_f64", ", %16, %17")) EXEC_RESTORE)        \
+    X(FMA_F64_LO32, "v_fma_f64, exec = lanes 0-31", 64, EXEC_SET("0xffffffff", "0") R8(EIGHT_D("v_fma_f64", ", %16, %17")) EXEC_RESTORE)    \
+    X(FMA_F64_SPREAD16, "v_fma_f64, exec = every fourth lane (16 lanes)", 64,                                                  \
+      EXEC_SET("0x11111111", "0x11111111") R8(EIGHT_D("v_fma_f64", ", %16, %17")) EXEC_RESTORE)                               \
+    X(FMA_F64_ONE, "v_fma_f64, exec = lane 0", 64, EXEC_SET("1", "0") R8(EIGHT_D("v_fma_f64", ", %16, %17")) EXEC_RESTORE)                \
+    X(FMA_F32_LO16, "v_fma_f32 (vgpr sources), exec = lanes 0-15", 64, EXEC_SET("0xffff", "0") R8(EIGHT_U("v_fma_f32", ", %18, %18")) EXEC_RESTORE) \
+    X(FMA_F32_LO32, "v_fma_f32 (vgpr sources), exec = lanes 0-31", 64, EXEC_SET("0xffffffff", "0") R8(EIGHT_U("v_fma_f32", ", %18, %18")) EXEC_RESTORE) \
+    X(CNDMASK_LO16, "v_cndmask_b32 (sgpr pair mask), exec = lanes 0-15", 64, EXEC_SET("0xffff", "0") R8(EIGHT_U("v_cndmask_b32", ", %18, s[40:41]")) EXEC_RESTORE) \
     X(MIX_HALF, "mix: 4 f64 (mul add fma mul) : 4 full-rate (fma_f32 and add_u32 mul_f32)", 64,                                \
       R8("v_mul_f64 %0, %0, %16\nv_fma_f32 %8, %8, %18, %18\nv_add_f64 %1, %1, %16\nv_and_b32 %9, %9, %18\n"                   \
          "v_fma_f64 %2, %2, %16, %17\nv_add_u32 %11, %11, %18\nv_mul_f64 %3, %3, %16\nv_mul_f32 %14, %14, %18\n"))             \
