@@ -60,30 +60,54 @@ def contexts():
         c.close()
 
 
-@pytest.mark.parametrize("seed", range(40))
-def test_random_scenes_all_strategies(contexts, oracle, seed):
+def _one_random_scene(contexts, oracle, rng, nobj, w, h, spp, depth, seed):
     from path_trace_golang_amd import capi, hip, scene
 
+    doc = _random_doc(rng, nobj)
+    o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=seed)
+    sc = scene.Scene.decode(doc)
+    for mode, ctx in contexts.items():
+        img = np.zeros((h, w, 4), np.uint8)
+        acc = np.zeros((h, w, 3))
+        nseg = np.zeros((h, w), np.uint32)
+        ndraw = np.zeros((h, w), np.uint32)
+        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc,
+                        nseg, ndraw, ctx=ctx)
+        assert st["segments"] == o["stats"]["segments"], (mode, seed)
+        assert st["draws"] == o["stats"]["draws"] and st["exit_scans"] == o["stats"]["exit_scans"], (mode, seed)
+        assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]), (mode, seed)
+        assert np.array_equal(img, o["rgba"]), (mode, seed)
+        ref = o["accum"]
+        ok = (np.isnan(acc) & np.isnan(ref)) | (np.abs(acc - ref) <= 4 * depth * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
+        assert np.all(ok), (mode, seed)
+    return o["stats"]["segments"]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_all_strategies(contexts, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
-    w, h, spp, depth = 32, 20, 3, 7
     for _ in range(4):
-        doc = _random_doc(rng, int(rng.integers(1, 45)) if _ < 3 else int(rng.integers(45, 150)))
-        o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=seed + 1)
-        sc = scene.Scene.decode(doc)
-        for mode, ctx in contexts.items():
-            img = np.zeros((h, w, 4), np.uint8)
-            acc = np.zeros((h, w, 3))
-            nseg = np.zeros((h, w), np.uint32)
-            ndraw = np.zeros((h, w), np.uint32)
-            st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed + 1, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc,
-                            nseg, ndraw, ctx=ctx)
-            assert st["segments"] == o["stats"]["segments"], (mode, seed)
-            assert st["draws"] == o["stats"]["draws"] and st["exit_scans"] == o["stats"]["exit_scans"], (mode, seed)
-            assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]), (mode, seed)
-            assert np.array_equal(img, o["rgba"]), (mode, seed)
-            ref = o["accum"]
-            ok = (np.isnan(acc) & np.isnan(ref)) | (np.abs(acc - ref) <= 4 * depth * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
-            assert np.all(ok), (mode, seed)
+        _one_random_scene(contexts, oracle, rng, int(rng.integers(1, 45)) if _ < 3 else int(rng.integers(45, 150)), 32, 20, 3, 7, seed + 1)
+
+
+@pytest.mark.skipif(not os.environ.get("PT_SOAK_SECONDS"), reason="long run: PT_SOAK_SECONDS=<seconds> [PT_SOAK_SEED=<n>]")
+def test_random_scenes_soak(contexts, oracle):
+    # the fuzz above with fresh seeds for as long as asked (evidence runs: profiles/r02_fuzz_soak.txt)
+    import time
+
+    t0, budget = time.time(), float(os.environ["PT_SOAK_SECONDS"])
+    rng = np.random.default_rng(int(os.environ.get("PT_SOAK_SEED", "90001")))
+    scenes = segs = 0
+    while time.time() - t0 < budget:
+        nobj = int(rng.integers(1, 45)) if rng.random() < 0.7 else int(rng.integers(45, 300))
+        w, h = int(rng.choice([8, 32, 33, 50])), int(rng.choice([8, 20, 33]))
+        segs += _one_random_scene(contexts, oracle, rng, nobj, w, h, int(rng.choice([1, 3, 6])), int(rng.choice([2, 7, 12])),
+                                  int(rng.integers(1, 1 << 40)))
+        scenes += 1
+        if scenes % 50 == 0:
+            print("soak: %d scenes, %.0f s" % (scenes, time.time() - t0), flush=True)  # a silent GPU job is taken to be hung
+    print("soak: %d random scenes x %d strategies, %d oracle segments each way, %.0f s, all equal" % (scenes, len(contexts), segs, time.time() - t0),
+          flush=True)
 
 
 def test_random_render_configurations_match_oracle(gpu_ctx, oracle):
