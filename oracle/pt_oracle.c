@@ -9,7 +9,7 @@
  * Deliberate differences from the reference, both forced by it:
  *   * RNG: the reference seeds math/rand from the wall clock per worker
  *     (random.go:14-16), so it has no reproducible stream.  Here every
- *     (seed, pixel, sample) owns a counter-based splitmix64 stream honouring the
+ *     (seed, pixel, sample) owns its own MWC64X stream (keyed by a splitmix64 hash) honouring the
  *     Float64 contract of random.go:27-34 (53-bit uniform in [0,1)).  Draw ORDER
  *     inside a sample is the reference's.
  *   * math.Exp: Go/amd64 uses an assembly routine; this follows the portable Go
@@ -196,6 +196,7 @@ double ora_pow(double x, double y) {
 /* ------------------------------------------------------------------ */
 
 #define GOLDEN 0x9E3779B97F4A7C15ULL
+#define MWC_A 4294883355ULL /* MWC64X multiplier (D. B. Thomas 2011); MWC_A * 2^32 - 1 is a safe prime */
 
 static uint64_t mix64(uint64_t z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
@@ -204,15 +205,26 @@ static uint64_t mix64(uint64_t z) {
     return z;
 }
 
+/* key = one splitmix64 finaliser over (seed key + (pixel << 32 | sample)); the MWC64X state is (x, c) = (low word,
+ * (high word >> 1) + 1): 0 < c < 2^31 < MWC_A keeps it off the generator's two fixed points. */
 uint64_t ora_stream_init(uint64_t seed, uint64_t pixel, uint64_t sample) {
-    uint64_t a = mix64(seed + GOLDEN);
-    uint64_t b = mix64(a + pixel);
-    return mix64(b + sample);
+    uint64_t h = mix64(mix64(seed + GOLDEN) + ((pixel << 32) | (sample & 0xffffffffULL)));
+    uint32_t x = (uint32_t)h, c = ((uint32_t)(h >> 32) >> 1) + 1u;
+    return ((uint64_t)c << 32) | x;
 }
 
+/* one MWC64X step: returns x ^ c, then (c, x) <- MWC_A * x + c */
+static uint32_t mwc64x(uint64_t *state) {
+    uint32_t x = (uint32_t)*state, c = (uint32_t)(*state >> 32);
+    *state = (uint64_t)x * MWC_A + c;
+    return x ^ c;
+}
+
+/* Float64 contract of random.go:27-34: a uniform multiple of 2^-53 in [0,1); 32 bits of one step over 21 of the next */
 double ora_stream_next(uint64_t *state) {
-    *state += GOLDEN;
-    return (double)(mix64(*state) >> 11) * (1.0 / 9007199254740992.0);
+    uint64_t hi = mwc64x(state);
+    uint64_t lo = mwc64x(state);
+    return (double)((hi << 21) | (lo >> 11)) * (1.0 / 9007199254740992.0);
 }
 
 typedef struct {

@@ -59,6 +59,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the p
 #define PT_BVH_WAVES 4  // blocks of 256 threads per CU (= waves per SIMD) the BVH kernels are compiled for
 #endif
 #define PT_HOLE 0xffffffffu     // job id of a reserved but unused queue slot
+// The host sizes every path-state queue as (entries a pass can append) + (waves of the widest writer grid) x (the larger
+// window): queue_slack() in ptcore.hip.  What that arithmetic relies on:
+static_assert(PT_QUEUE_BLOCK >= PT_WAVE && PT_CONT_BLOCK >= PT_WAVE, "a window must hold one push of a whole wave");
+static_assert(PT_QUEUE_BLOCK <= PT_CONT_BLOCK, "queue_slack() prices every window at PT_CONT_BLOCK slots");
+static_assert(PT_BLOCK % PT_WAVE == 0, "whole waves per block");
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_init_kernel(const WfArgs A) {
                             1.0, 1.0, B.ray_rng[i], i, F.max_depth, -1, 0u, nd, STATS, B.counters + 19);
             }
         }
-        if (job == PT_HOLE) A.qin.job[i] = PT_HOLE;
+        if (job == PT_HOLE && i < A.qin.cap) A.qin.job[i] = PT_HOLE;
     }
     const uint32_t w_s = wave_sum(c_samples), w_d = wave_sum(c_draw);
     if ((threadIdx.x & (PT_WAVE - 1)) == 0) {

@@ -84,7 +84,7 @@ struct Device {
     DevBuf<BroadSphere> bsph;
     DevBuf<BroadBox> bbox;
     DevBuf<int32_t> plane_idx;
-    size_t jobs_cap = 0;              // jobs per pass this device could hold after an allocation failed (0: never failed)
+    size_t bytes_cap = 0;             // bytes of per-pass buffers (jobs + path-state queues) that fitted after an allocation failed (0: never failed)
     DevBuf<BvhNode> bvh_nodes;
     DevBuf<BvhObj> bvh_objs;
     DevBuf<double> L;
@@ -435,6 +435,9 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     for (int32_t i : fr.plane_idx) {
         const DevObj &o = world[(size_t)i];
         if (!(o.b[0] == 0.0 && o.b[1] == 1.0 && o.b[2] == 0.0) || std::signbit(o.b[0]) || std::signbit(o.b[2])) F.planes_y = 0;
+        // plane_exact_y drops the terms (px - ox) * 0 and (pz - oz) * 0 of objects.go:107: they are zeros only for a finite point
+        // (inf * 0 = NaN makes the reference's t a NaN, which its range test accepts)
+        if (!(std::isfinite(o.a[0]) && std::isfinite(o.a[1]) && std::isfinite(o.a[2]))) F.planes_y = 0;
     }
     F.n_dsph = (int32_t)fr.bsph_diel.size();
     F.n_dbox = (int32_t)fr.bbox_diel.size();
@@ -517,6 +520,39 @@ int32_t dev_events(Device &d, std::vector<EventPair> &v, size_t need) {
     return PT_OK;
 }
 
+#define PT_GLASS_MAX_BLOCKS_PER_CU 8
+
+// Slots a path-state queue needs beyond one per job of the pass: every wave of a pass that appends to it reserves slots in
+// windows (one atomic per window, see trace_kernel) and may leave its last window partly empty -- fewer than one window per
+// wave and pass.  Derived from the very grids the launches use (dev_step, dev_step_wavefront), none of which is wider
+// than one block per PT_BLOCK items of the pass:
+//   split form      glass queue <- trace_kernel<split> (num_cu x blocks_per_cu_split blocks, windows of PT_QUEUE_BLOCK)
+//                   continuation queue <- glass_kernel (num_cu x blocks_per_cu_glass blocks, windows of PT_CONT_BLOCK)
+//   wavefront form  path queue <- wf_shade_kernel AND wf_exit_kernel of one level (num_cu x PT_WF_PASS_BLOCKS_PER_CU blocks each)
+// every window priced at PT_CONT_BLOCK (static_assert in pt_kernels.h: PT_QUEUE_BLOCK <= PT_CONT_BLOCK).
+#define PT_WF_PASS_BLOCKS_PER_CU 4
+size_t queue_slack(const pt_ctx *ctx, const Device &d, size_t njobs_max) {
+    const Frame &fr = ctx->frame;
+    const size_t grid_cap = std::max<size_t>(1, (njobs_max + PT_BLOCK - 1) / PT_BLOCK);
+    size_t writer_blocks;
+    if (fr.wavefront)
+        writer_blocks = 2 * std::min<size_t>((size_t)d.num_cu * PT_WF_PASS_BLOCKS_PER_CU, grid_cap);
+    else
+        writer_blocks = std::min<size_t>((size_t)d.num_cu * (size_t)std::max(d.blocks_per_cu_split, d.blocks_per_cu_glass), grid_cap);
+    return writer_blocks * (PT_BLOCK / PT_WAVE) * PT_CONT_BLOCK;
+}
+
+// the samples per pass were chosen from the buffer budget (not forced by pt_config.spp_chunk)
+bool cfg_chunk_free(const Frame &fr) { return fr.cfg.spp_chunk <= 0; }
+
+// equal passes: ceil(spp / chunk) passes of ceil(spp / passes) samples instead of full passes and a short last one
+void balance_chunk(Frame &fr) {
+    const uint32_t spp = (uint32_t)std::max(1, fr.cfg.samples_per_px);
+    if (fr.chunk >= spp) { fr.chunk = spp; return; }
+    const uint32_t passes = (spp + fr.chunk - 1) / fr.chunk;
+    fr.chunk = (spp + passes - 1) / passes;
+}
+
 int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t stream) {
     Frame &fr = ctx->frame;
     const SceneData &sd = ctx->sd;
@@ -573,56 +609,11 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         HIP_TRY(d.acc_seg.reserve(ns));
         HIP_TRY(d.acc_draw.reserve(ns));
     }
-    // per-chunk job buffers; when the device cannot give that much right now the chunk is halved until it can
-    // (the ordered accumulation makes the pixels independent of the chunk size)
-    // (a device that once could not give the budget keeps the size that fitted: trying the full budget again on every frame
-    // costs seconds of hipMalloc / hipFree per frame when two processes share one GPU)
-    if (d.jobs_cap && (size_t)ns * fr.chunk > d.jobs_cap) fr.chunk = (uint32_t)std::max<size_t>(1, d.jobs_cap / ns);
-    for (;;) {
-        const size_t njobs_max = (size_t)ns * fr.chunk;
-        hipError_t e = d.L.reserve(4 * njobs_max);
-        if (e == hipSuccess) e = d.ray.reserve(6 * njobs_max);
-        if (e == hipSuccess) e = d.ray_rng.reserve(njobs_max);
-        if (e == hipSuccess) e = d.ray_ndraw.reserve(njobs_max);
-        if (e == hipSuccess && fr.stats_on) e = d.job_seg.reserve(njobs_max);
-        if (e == hipSuccess && fr.stats_on) e = d.job_draw.reserve(njobs_max);
-        if (fr.wavefront || (fr.split_rounds > 0 && fr.has_glass)) {  // path-state queues: 10 doubles + stream state + job, depth, hit object (+ 2 counters) per entry, twice
-            // one entry per job at most, plus the slots the waves of a trace pass reserve in blocks and may leave empty
-            const size_t qcap = njobs_max + (size_t)d.num_cu * 32u * PT_CONT_BLOCK;
-            const size_t planes = fr.stats_on ? 6 : 4;
-            if (e == hipSuccess) e = d.gq_d.reserve(10 * qcap);
-            if (e == hipSuccess) e = d.cq_d.reserve(10 * qcap);
-            if (e == hipSuccess) e = d.gq_rs.reserve(qcap);
-            if (e == hipSuccess) e = d.cq_rs.reserve(qcap);
-            if (e == hipSuccess) e = d.gq_u32.reserve(planes * qcap);
-            if (e == hipSuccess) e = d.cq_u32.reserve(planes * qcap);
-            if (fr.wavefront) {
-                if (e == hipSuccess) e = d.xq_d.reserve(10 * qcap);
-                if (e == hipSuccess) e = d.xq_rs.reserve(qcap);
-                if (e == hipSuccess) e = d.xq_u32.reserve(planes * qcap);
-                if (ctx->wf_sort) {
-                    if (e == hipSuccess) e = d.wf_perm.reserve(qcap);
-                    if (e == hipSuccess) e = d.wf_key.reserve(qcap);
-                    if (e == hipSuccess) e = d.wf_bins.reserve(PT_WF_BINS + 8);
-                }
-            }
-            d.q_cap = qcap;
-        }
-        if (e == hipSuccess) break;
-        (void)hipGetLastError();
-        if (e != hipErrorOutOfMemory || fr.chunk <= 1) return fail(PT_ERR_HIP, std::string("job buffers: ") + hipGetErrorString(e));
-        d.L.release(); d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release(); d.job_seg.release(); d.job_draw.release();
-        d.gq_d.release(); d.cq_d.release(); d.gq_rs.release(); d.cq_rs.release(); d.gq_u32.release(); d.cq_u32.release();
-        d.xq_d.release(); d.xq_rs.release(); d.xq_u32.release();
-        fr.chunk = std::max<uint32_t>(1, fr.chunk / 2);
-        d.jobs_cap = (size_t)ns * fr.chunk;
-        if (std::getenv("PTCORE_VERBOSE")) std::fprintf(stderr, "ptcore: device %d is short of memory, samples per pass reduced to %u\n", d.ordinal, fr.chunk);
-    }
     if (!d.ev_first) {
         HIP_TRY(hipEventCreate(&d.ev_first));
         HIP_TRY(hipEventCreate(&d.ev_last));
     }
-    // occupancy of the trace kernel for this scene's LDS footprint
+    // occupancy of the kernels of this frame for the scene's LDS footprint (before the buffers: the queue slack depends on it)
     const size_t lds = fr.lds_bytes;
     int nb = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan), PT_BLOCK, lds));
@@ -639,7 +630,88 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, true), PT_BLOCK, lds));
         d.blocks_per_cu_split = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_glass(fr.stats_on, fr.scan), PT_BLOCK, fr.glass_lds_bytes));
-        d.blocks_per_cu_glass = std::max(1, std::min(nb, 8));
+        d.blocks_per_cu_glass = std::max(1, std::min(nb, PT_GLASS_MAX_BLOCKS_PER_CU));
+    }
+    // per-pass buffers: 90 B per job (radiance record, primary ray, stream state, draw count; + 8 B with pixel stats) and, for the
+    // forms that park paths in HBM, two or three path-state queues
+    const bool queues = fr.wavefront || (fr.split_rounds > 0 && fr.has_glass);
+    const size_t nqueues = !queues ? 0 : fr.wavefront ? 3 : 2;
+    const size_t qplanes = fr.stats_on ? 6 : 4;
+    const size_t qentry = 10 * sizeof(double) + sizeof(unsigned long long) + qplanes * sizeof(uint32_t);
+    const size_t job_bytes = 4 * sizeof(double) + 6 * sizeof(double) + sizeof(unsigned long long) + sizeof(uint16_t) +
+                             (fr.stats_on ? 2 * sizeof(uint32_t) : 0);
+    auto queue_cap = [&](size_t njobs_max) { return njobs_max + queue_slack(ctx, d, njobs_max); };
+    auto need_bytes = [&](uint32_t chunk) {
+        const size_t nj = (size_t)ns * chunk;
+        return nj * job_bytes + nqueues * queue_cap(nj) * qentry + (fr.wavefront && ctx->wf_sort ? 2 * queue_cap(nj) * sizeof(uint32_t) : 0);
+    };
+    auto held_bytes = [&]() {
+        return d.L.cap * sizeof(double) + d.ray.cap * sizeof(double) + d.ray_rng.cap * 8 + d.ray_ndraw.cap * 2 + (d.job_seg.cap + d.job_draw.cap) * 4 +
+               (d.gq_d.cap + d.cq_d.cap + d.xq_d.cap) * sizeof(double) + (d.gq_rs.cap + d.cq_rs.cap + d.xq_rs.cap) * 8 +
+               (d.gq_u32.cap + d.cq_u32.cap + d.xq_u32.cap + d.wf_perm.cap + d.wf_key.cap) * 4;
+    };
+    // The budget covers everything a pass holds, the window slack of the queues included: when the queues push the total over it,
+    // the samples per pass shrink (a frame is cut into more passes; pixels do not depend on that).
+    if (cfg_chunk_free(fr) && need_bytes(fr.chunk) > ctx->l_budget_bytes) {
+        const size_t fixed = need_bytes(1) > (size_t)ns * (job_bytes + nqueues * qentry) ? need_bytes(1) - (size_t)ns * (job_bytes + nqueues * qentry) : 0;
+        const size_t per = (size_t)ns * (job_bytes + nqueues * qentry);
+        fr.chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes > fixed ? (ctx->l_budget_bytes - fixed) / per : 1);
+        while (fr.chunk > 1 && need_bytes(fr.chunk) > ctx->l_budget_bytes) fr.chunk -= std::max(1u, fr.chunk / 64u);
+        balance_chunk(fr);
+    }
+    // A device that once could not give the budget keeps the size that fitted (trying the full budget again on every frame costs
+    // seconds of hipMalloc / hipFree per frame when two processes share one GPU) -- until the device shows room for it again.
+    if (d.bytes_cap && need_bytes(fr.chunk) > d.bytes_cap) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + held_bytes() >= need_bytes(fr.chunk) + need_bytes(fr.chunk) / 16) {
+            d.bytes_cap = 0;  // whatever took the memory is gone: back to the full size
+        } else {
+            while (fr.chunk > 1 && need_bytes(fr.chunk) > d.bytes_cap) fr.chunk = std::max<uint32_t>(1, fr.chunk / 2);
+        }
+    }
+    // when the device cannot give that much right now the chunk is halved until it can
+    // (the ordered accumulation makes the pixels independent of the chunk size)
+    for (;;) {
+        const size_t njobs_max = (size_t)ns * fr.chunk;
+        hipError_t e = d.L.reserve(4 * njobs_max);
+        if (e == hipSuccess) e = d.ray.reserve(6 * njobs_max);
+        if (e == hipSuccess) e = d.ray_rng.reserve(njobs_max);
+        if (e == hipSuccess) e = d.ray_ndraw.reserve(njobs_max);
+        if (e == hipSuccess && fr.stats_on) e = d.job_seg.reserve(njobs_max);
+        if (e == hipSuccess && fr.stats_on) e = d.job_draw.reserve(njobs_max);
+        if (queues) {  // path-state queues: 10 doubles + stream state + job, depth, hit object, answer (+ 2 counters) per entry
+            // one entry per job at most, plus the slots the waves of the writing passes reserve in windows and may leave empty
+            size_t qcap = queue_cap(njobs_max);
+            // PTCORE_DEBUG_QUEUE_CAP=<entries> (tests only): queues too small for the frame, to show that an overflow fails the
+            // frame with PT_ERR_STATE instead of writing outside them
+            if (const char *dbg = std::getenv("PTCORE_DEBUG_QUEUE_CAP")) qcap = (size_t)std::max(64L, std::atol(dbg));
+            if (e == hipSuccess) e = d.gq_d.reserve(10 * qcap);
+            if (e == hipSuccess) e = d.cq_d.reserve(10 * qcap);
+            if (e == hipSuccess) e = d.gq_rs.reserve(qcap);
+            if (e == hipSuccess) e = d.cq_rs.reserve(qcap);
+            if (e == hipSuccess) e = d.gq_u32.reserve(qplanes * qcap);
+            if (e == hipSuccess) e = d.cq_u32.reserve(qplanes * qcap);
+            if (fr.wavefront) {
+                if (e == hipSuccess) e = d.xq_d.reserve(10 * qcap);
+                if (e == hipSuccess) e = d.xq_rs.reserve(qcap);
+                if (e == hipSuccess) e = d.xq_u32.reserve(qplanes * qcap);
+                if (ctx->wf_sort) {
+                    if (e == hipSuccess) e = d.wf_perm.reserve(qcap);
+                    if (e == hipSuccess) e = d.wf_key.reserve(qcap);
+                    if (e == hipSuccess) e = d.wf_bins.reserve(PT_WF_BINS + 8);
+                }
+            }
+            d.q_cap = qcap;
+        }
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || fr.chunk <= 1) return fail(PT_ERR_HIP, std::string("job buffers: ") + hipGetErrorString(e));
+        d.L.release(); d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release(); d.job_seg.release(); d.job_draw.release();
+        d.gq_d.release(); d.cq_d.release(); d.gq_rs.release(); d.cq_rs.release(); d.gq_u32.release(); d.cq_u32.release();
+        d.xq_d.release(); d.xq_rs.release(); d.xq_u32.release(); d.wf_perm.release(); d.wf_key.release();
+        fr.chunk = std::max<uint32_t>(1, fr.chunk / 2);
+        d.bytes_cap = need_bytes(fr.chunk);
+        if (std::getenv("PTCORE_VERBOSE")) std::fprintf(stderr, "ptcore: device %d is short of memory, samples per pass reduced to %u\n", d.ordinal, fr.chunk);
     }
     return PT_OK;
 }
@@ -681,10 +753,10 @@ int32_t dev_step_wavefront(pt_ctx *ctx, Device &d, const DevFrame &F, const Trac
     const size_t lds_scan = fr.lds_bytes, lds_shade = fr.shade_lds_bytes, lds_mat = (size_t)F.nmat * sizeof(DevMat);
     const uint32_t blocks_all = (F.njobs + PT_BLOCK - 1) / PT_BLOCK;
     const uint32_t grid_scan = std::max(1u, std::min((uint32_t)(d.num_cu * d.blocks_per_cu_wf), blocks_all));
-    // shading passes: four blocks per CU.  Their waves append to the next level's queue in windows of PT_CONT_BLOCK slots
-    // (one atomic per window: a pass this short cannot afford more on one address); shade + exit pass together leave at most
-    // 2 x (num_cu x 16 waves) x PT_CONT_BLOCK slots empty, which is the margin the queues are allocated with.
-    const uint32_t grid_pass = std::max(1u, std::min((uint32_t)(d.num_cu * 4), blocks_all));
+    // shading passes: PT_WF_PASS_BLOCKS_PER_CU blocks per CU.  Their waves append to the next level's queue in windows of
+    // PT_CONT_BLOCK slots (one atomic per window: a pass this short cannot afford more on one address); shade + exit pass
+    // together leave at most 2 x grid_pass x 4 waves x PT_CONT_BLOCK slots empty, which is what queue_slack() allocates.
+    const uint32_t grid_pass = std::max(1u, std::min((uint32_t)(d.num_cu * PT_WF_PASS_BLOCKS_PER_CU), blocks_all));
     const int levels = std::max(0, fr.cfg.max_depth);
     if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + 2 * (size_t)levels + 1)) return rc;
     if (int32_t rc = dev_events(d, d.ev_glass, d.n_glass + 3 * (size_t)levels + 2)) return rc;
@@ -875,8 +947,9 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
             A.sky = fr.sky;
             A.B = B;
             uint32_t grid = (uint32_t)(d.num_cu * (split ? d.blocks_per_cu_split : d.blocks_per_cu));
-            if (first) grid = std::min(grid, (waves_needed + 3u) / 4u);  // later passes: the item count lives on the device
-            grid = std::max(1u, grid);
+            // (later passes: the item count lives on the device; no pass holds more items than the chunk has jobs, which is also
+            // the bound queue_slack() assumes)
+            grid = std::max(1u, std::min(grid, (waves_needed + 3u) / 4u));
             if (d.trace_is_split.size() <= d.n_trace) d.trace_is_split.resize(d.n_trace + 1);
             d.trace_is_split[d.n_trace] = split ? 1 : 0;
             EventPair &e = d.ev_trace[d.n_trace++];
@@ -891,7 +964,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
         } else {
             // Split passes: trace (dielectric hits -> glass queue), glass (-> continuation queue), `rounds` times; what is
             // still under way then (paths with more than `rounds` dielectric bounces) finishes in the all-in-one form.
-            const uint32_t glass_grid = std::max(1u, std::min((uint32_t)(d.num_cu * d.blocks_per_cu_glass), (F.njobs + PT_BLOCK - 1) / PT_BLOCK));
+            const uint32_t glass_grid = std::max(1u, std::min((uint32_t)(d.num_cu * d.blocks_per_cu_glass), (F.njobs + PT_BLOCK - 1) / PT_BLOCK));  // same bound as queue_slack()
             for (int r = 0; r < rounds; r++) {
                 if (r > 0) HIP_TRY(hipMemsetAsync(qw, 0, 2 * sizeof(unsigned int), d.stream));  // cursor and glass count
                 unsigned int *c_in = r == 0 ? qw + 4 : qw + 2 + (r & 1), *c_out = qw + 2 + ((r + 1) & 1);
@@ -1081,6 +1154,15 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     }
     if ((scan == ptk::SCAN_BROAD_WIDE || scan == ptk::SCAN_VERIFY_WIDE) && !wide_ok && F.broad_ok != 1)
         scan = scan == ptk::SCAN_VERIFY_WIDE ? ptk::SCAN_VERIFY_BVH : ptk::SCAN_BVH;
+    // A NaN or an infinity in the geometry (reachable through the C ABI, not through the JSON loader) makes the reference's own
+    // tests return NaN parameters, which its range tests accept (NaN compares false, objects.go:56-60, :110) and which then
+    // poison `closest` for every later object of the loop.  Only the loop itself reproduces that: such a world takes the
+    // plain object-by-object scan, whatever was asked for.
+    for (const DevObj &o : sd.world) {
+        bool fin = std::isfinite(o.radius);
+        for (int k = 0; k < 3; k++) fin = fin && std::isfinite(o.a[k]) && std::isfinite(o.b[k]);
+        if (!fin) scan = ptk::SCAN_UNIFORM;
+    }
     sd.scan = scan;
     const bool big = scan == ptk::SCAN_BVH || scan == ptk::SCAN_VERIFY_BVH;
     sd.bvh_nodes.clear();
@@ -1221,6 +1303,7 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     chunk = std::min<uint32_t>(chunk, (uint32_t)std::max(1, cfg->samples_per_px));
     chunk = std::min<uint32_t>(chunk, std::max(1u, 0x7fffffffu / slots));
     fr.chunk = chunk;
+    if (cfg->spp_chunk <= 0) balance_chunk(fr);
     fr.done_spp = 0;
     fr.t0 = std::chrono::steady_clock::now();
     fr.open = true;

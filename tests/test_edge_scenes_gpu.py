@@ -130,3 +130,17 @@ def test_unknown_object_material_and_sky_types_follow_the_reference(gpu_ctx, ora
     _check(gpu_ctx, oracle, {"camera": CAM, "sky": SKY, "objects": objs[:2], "materials": mats})
     _check(gpu_ctx, oracle, {"camera": CAM, "sky": SKY, "objects": [objs[0], objs[2]], "materials": mats})
     _check(gpu_ctx, oracle, {"camera": CAM, "sky": weird_sky, "background": bg, "objects": [], "materials": []})
+
+
+def test_non_finite_geometry_follows_the_reference_loop(gpu_ctx, oracle):
+    # a plane whose point has an infinite x: (px - ox) * 0 = NaN, t = NaN, and `t < tMin || t > tMax` lets it through
+    # (objects.go:107-112); the NaN then sits in `closest` for the objects after it.  Same for a sphere with a NaN centre.
+    inf, nan = float("inf"), float("nan")
+    base = [{"type": "sphere", "position": V(-1.2, 1, 0), "size": V(0.8, 0, 0), "material_id": "m"},
+            {"type": "box", "position": V(1.2, 0.6, 0), "size": V(1, 1.2, 1), "material_id": "d"}]
+    for odd in ({"type": "plane", "position": V(inf, 0, 0), "material_id": "d"},
+                {"type": "plane", "position": V(0, 0, -inf), "material_id": "d"},
+                {"type": "sphere", "position": V(nan, 1, 0), "size": V(0.5, 0, 0), "material_id": "g"},
+                {"type": "box", "position": V(0, inf, 0), "size": V(1, 1, 1), "material_id": "d"}):
+        for objs in (base + [odd], [odd] + base):
+            _check(gpu_ctx, oracle, {"camera": CAM, "sky": SKY, "objects": objs, "materials": MATS}, w=32, h=20, spp=2, depth=5)

@@ -77,10 +77,66 @@ def test_stream_contract(oracle):
     # streams are keyed by (seed, pixel, sample)
     keys = {L.ora_stream_init(s, p, k) for s in (1, 2) for p in range(50) for k in range(50)}
     assert len(keys) == 2 * 50 * 50
-    # splitmix64 known answer: state 0 -> first output
-    s0 = C.c_uint64(0)
-    L.ora_stream_next(C.byref(s0))
-    assert s0.value == 0x9E3779B97F4A7C15
+    # MWC64X known answers from an independent restatement (Python integers): the state after a draw and the draw itself
+    A = 4294883355
+    for start in (0x0000000100000001, 0x7fffffff_ffffffff, 0x12345678_9abcdef0):
+        x, c = start & 0xffffffff, start >> 32
+        outs = []
+        for _ in range(2):
+            outs.append(x ^ c)
+            t = x * A + c
+            x, c = t & 0xffffffff, t >> 32
+        s0 = C.c_uint64(start)
+        got = L.ora_stream_next(C.byref(s0))
+        assert s0.value == (c << 32) | x
+        assert got == ((outs[0] << 21) | (outs[1] >> 11)) / 2.0 ** 53
+    # the carry of a fresh stream is in [1, 2^31]: never a fixed point of the generator ((0, 0) would draw 0.0 for ever and
+    # hang the rejection loops of math.go:74-84)
+    for s in (1, 2, 3):
+        for p in (0, 1, 2 ** 28 - 1):
+            for k in (0, 1, 2 ** 31 - 1):
+                assert 1 <= (L.ora_stream_init(s, p, k) >> 32) <= 2 ** 31
+
+
+def test_stream_quality(oracle):
+    """The stream is this package's own definition (the reference seeds from the clock): check what the renderer relies on.
+    Many short streams keyed by neighbouring (pixel, sample), as a frame uses them: every draw position uniform, consecutive
+    draws (the (u, v), (r1, r2) and rejection-triple draws) jointly uniform, same position of neighbouring samples
+    jointly uniform.  z-scores of chi-square statistics; a defective generator gives tens to thousands."""
+    L = oracle.lib()
+    nd, npix, ns = 8, 600, 32
+    d = np.empty((npix * ns, nd))
+    i = 0
+    for p in range(npix):
+        for k in range(ns):
+            st = C.c_uint64(L.ora_stream_init(7, 1000 + p, k))
+            for j in range(nd):
+                d[i, j] = L.ora_stream_next(C.byref(st))
+            i += 1
+    n = d.shape[0]
+
+    def z(counts):
+        nb = counts.size
+        e = counts.sum() / nb
+        return (((counts - e) ** 2 / e).sum() - (nb - 1)) / math.sqrt(2.0 * (nb - 1))
+
+    for j in range(nd):
+        assert abs(z(np.bincount((d[:, j] * 64).astype(int), minlength=64))) < 5
+        assert abs(d[:, j].mean() - 0.5) < 4 / math.sqrt(12 * n)
+    for j in range(nd - 1):
+        cell = (d[:, j] * 16).astype(int) * 16 + (d[:, j + 1] * 16).astype(int)
+        assert abs(z(np.bincount(cell, minlength=256))) < 5
+        assert abs(np.corrcoef(d[:, j], d[:, j + 1])[0, 1]) < 5 / math.sqrt(n)
+    for j in range(nd - 2):
+        cell = ((d[:, j] * 8).astype(int) * 8 + (d[:, j + 1] * 8).astype(int)) * 8 + (d[:, j + 2] * 8).astype(int)
+        assert abs(z(np.bincount(cell, minlength=512))) < 5
+    nxt = d.reshape(npix, ns, nd)
+    for j in range(nd):  # sample k against sample k + 1 of the same pixel
+        a, b = nxt[:, :-1, j].ravel(), nxt[:, 1:, j].ravel()
+        assert abs(z(np.bincount((a * 16).astype(int) * 16 + (b * 16).astype(int), minlength=256))) < 5
+    # the low bits of the 53-bit grid come from the second generator step
+    low = (d[:, 0] * 2.0 ** 53).astype(np.uint64) & np.uint64(255)
+    assert abs(z(np.bincount(low.astype(int), minlength=256))) < 5
 
 
 # ----------------------------------------------------------------- primitives (objects.go)

@@ -41,6 +41,17 @@ def test_reference_scenes_in_the_wavefront_form(monkeypatch, oracle, gpu_ctx, na
     _same_as_oracle(o, *_render(monkeypatch, scene.load(scene_path(name)), w, h, spp, depth, 4, False), depth)
 
 
+@pytest.mark.parametrize("name,depth", [("metal_glass_room", 14), ("gpu_showcase", 21)])
+def test_deep_paths_take_the_early_out_of_the_level_loop(monkeypatch, oracle, gpu_ctx, name, depth):
+    """From level 8 on the host reads the number of paths left every fourth level and stops when there are none
+    (csrc/ptcore.hip, dev_step_wavefront): only reachable with max_depth >= 10 -- the "final" preset asks for 80."""
+    from path_trace_golang_amd import scene
+
+    w, h, spp = 64, 36, 3
+    o = oracle.render(oracle.Scene.load(scene_path(name)), w, h, spp, depth, seed=8)
+    _same_as_oracle(o, *_render(monkeypatch, scene.load(scene_path(name)), w, h, spp, depth, 8, False), depth)
+
+
 @pytest.mark.parametrize("sort", [False, True])
 def test_bvh_scene_in_the_wavefront_form(monkeypatch, oracle, gpu_ctx, sort):
     from path_trace_golang_amd import synth
