@@ -243,7 +243,7 @@ inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> 
         std::memset(&nd, 0, sizeof nd);
         nd.node_base = (int32_t)queue.size();
         nd.obj_base = (int32_t)out.order.size();
-        uint32_t ranks = 0, intm = 0, objm = 0;
+        uint32_t ranks = 0, intm = 0, objm = 0, boxm = 0;
         int ni = 0, no = 0;
         for (int s = 0; s < WIDTH; s++) {
             if (s >= ns) {  // empty slot: never flagged in the masks; the box is a far-away point
@@ -266,6 +266,7 @@ inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> 
             if (c.obj >= 0) {
                 ranks |= (uint32_t)no << (2 * s);
                 objm |= 1u << s;
+                if ((world[(size_t)c.obj].kind & 0xff) == KIND_BOX) boxm |= 1u << s;
                 out.order.push_back(c.obj);
                 no++;
             } else {
@@ -276,7 +277,7 @@ inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> 
                 ni++;
             }
         }
-        nd.meta = ranks | (intm << 8) | (objm << 12) | ((~intm & 0xfu) << 16);
+        nd.meta = ranks | (intm << 8) | (objm << 12) | (boxm << 16);
         out.nodes.push_back(nd);
         out.depth = std::max(out.depth, level[q]);
     }
@@ -291,6 +292,74 @@ inline Built build(const std::vector<DevObj> &world, const std::vector<int32_t> 
     }
     out.stack_need = need[0];
     return out;
+}
+
+// The certain core of an object (pt_walk32.h): a box every point of which lies inside the object by the margin m.  A ray
+// that passes through it is hit by the reference's FP64 test of the object (objects.go:37-61, :141-179) no later than where
+// it enters the core: the FP32 slab arithmetic of the walk is off by <= 1.2e-6 B in position, two orders of magnitude less
+// than m = B / 4096.
+//   box     [min + m, max - m]; only a proper box (min < max on every axis: anything else the slab test never hits)
+//   sphere  the cube of half side (|r| - m) / sqrt(3) about the centre (the reference squares the radius: its sign is irrelevant)
+// Returns false when the object has no core (thinner than 2 m, degenerate, not finite).
+inline bool object_core(const DevObj &o, double m, double lo[3], double hi[3]) {
+    if (!(m > 0) || !std::isfinite(m)) return false;
+    const int kind = o.kind & 0xff;
+    if (kind == KIND_SPHERE) {
+        const double r = std::fabs(o.radius);
+        const double q = (r - m) * 0.57735026 * (1.0 - 1e-9);
+        if (!(q > 0.25 * m) || !std::isfinite(q)) return false;
+        for (int k = 0; k < 3; k++) { lo[k] = o.a[k] - q; hi[k] = o.a[k] + q; }
+    } else if (kind == KIND_BOX) {
+        for (int k = 0; k < 3; k++) {
+            if (!(o.a[k] < o.b[k])) return false;
+            lo[k] = o.a[k] + m;
+            hi[k] = o.b[k] - m;
+            if (!(hi[k] - lo[k] > 0.5 * m)) return false;
+        }
+    } else {
+        return false;
+    }
+    for (int k = 0; k < 3; k++)
+        if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return false;
+    return true;
+}
+
+// Core twins of the nodes of `b`: twin q holds, in slot s, a box INSIDE the core of the object in slot s of node q, as FP32
+// centre / half extent rounded INWARD (meta bits 12-15: the slot has a core; no internal slots).  Also marks in the NODE's
+// meta (bits 20-23) which object slots have a core.
+inline std::vector<BvhNode> build_cores(Built &b, const std::vector<DevObj> &world, double margin) {
+    std::vector<BvhNode> cores(b.nodes.size());
+    for (size_t q = 0; q < b.nodes.size(); q++) {
+        BvhNode &nd = b.nodes[q];
+        BvhNode tw;
+        std::memset(&tw, 0, sizeof tw);
+        uint32_t has = 0;
+        for (int s = 0; s < WIDTH; s++) {
+            for (int k = 0; k < 3; k++) { tw.c[k][s] = 3.0e38f; tw.h[k][s] = 0.0f; }
+            if (!((nd.meta >> (12 + s)) & 1u)) continue;
+            const int32_t oi = b.order[(size_t)(nd.obj_base + (int)((nd.meta >> (2 * s)) & 3u))];
+            double lo[3], hi[3];
+            if (!object_core(world[(size_t)oi], margin, lo, hi)) continue;
+            float c[3], h[3];
+            bool ok = true;
+            for (int k = 0; k < 3; k++) {
+                const float cf = (float)(0.5 * lo[k] + 0.5 * hi[k]);
+                const double g = std::min((double)cf - lo[k], hi[k] - (double)cf);  // [cf - g, cf + g] lies inside [lo, hi]
+                // cf - hf and cf + hf are formed in FP32 by the walk (c*iv - h*|iv|): keep two more ulps of the larger magnitude clear
+                const float hf = detail::down(g - 2.0 * 1.1920929e-7 * (std::fabs((double)cf) + std::fabs(g)));
+                ok = ok && hf > 0 && std::isfinite(cf) && std::isfinite(hf);
+                c[k] = cf;
+                h[k] = hf;
+            }
+            if (!ok) continue;
+            for (int k = 0; k < 3; k++) { tw.c[k][s] = c[k]; tw.h[k][s] = h[k]; }
+            has |= 1u << s;
+        }
+        tw.meta = has << 12;
+        nd.meta = (nd.meta & ~(0xfu << 20)) | (has << 20);
+        cores[q] = tw;
+    }
+    return cores;
 }
 
 }  // namespace ptbvh

@@ -74,9 +74,13 @@ static_assert(sizeof(BroadBox) == 32, "BroadBox layout");
 // empty, with the slot's FP32 box (inflated, rounded outward; as centre and half extent) stored slot-minor so one
 // 16-byte load brings the same number of all four.  Nodes are numbered breadth-first: the internal children of a
 // node are node_base + rank, its object children bvh_objs[obj_base + rank].
-//   meta bits 0-7: rank of slot s within its kind at bits [2s, 2s+2); 8-11: slot is an internal node;
-//   12-15: slot is an object; 16-19: slot is NOT an internal node (complement of 8-11).
-struct alignas(128) BvhNode {   // one 128-byte cache line per node (112 bytes used)
+//   meta bits 0-7: rank of slot s within its kind at bits [2s, 2s+2); 8-11: slot is an internal node; 12-15: slot is an
+//   object; 16-19: the slot's object is a box (else a sphere); 20-23: the slot's object has a certain core in the node's
+//   twin (pt_bvh.h build_cores, pt_walk32.h).
+// (Round 3 also built and measured a 48-byte node -- the slot boxes on an 8-bit grid of the node's own, three 16-byte loads
+// per visit instead of seven: profiles/r03_qnode_ab.txt.  The walks are bound by vector-instruction issue, not by the
+// loads: the 35 instructions that decode such a node cost more than its four saved loads give back.)
+struct alignas(128) BvhNode {   // one 128-byte cache line per node (108 bytes used)
     float c[3][4];    // [axis][slot] centre of the slot's inflated box
     float h[3][4];    // half extent, rounded up so that [c - h, c + h] holds it (the slab test is then three fma per axis and slot
                       // pair, no min / max to order the planes: see PT_BOX_SLABS in pt_kernels.h)
@@ -86,6 +90,11 @@ struct alignas(128) BvhNode {   // one 128-byte cache line per node (112 bytes u
     int32_t pad[5];
 };
 static_assert(sizeof(BvhNode) == 128, "BvhNode layout");
+
+inline int32_t bvh_node_base(const BvhNode &n) { return n.node_base; }
+inline int32_t bvh_obj_base(const BvhNode &n) { return n.obj_base; }
+inline double bvh_slot_lo(const BvhNode &n, int k, int s) { return (double)n.c[k][s] - (double)n.h[k][s]; }
+inline double bvh_slot_hi(const BvhNode &n, int k, int s) { return (double)n.c[k][s] + (double)n.h[k][s]; }
 
 // Object as stored in node order for the BVH path: the 80-byte DevObj plus its index in file order
 // (tie rules and the winner look-up use the original index).
@@ -184,6 +193,7 @@ struct TraceBuffers {
     const int32_t *plane_idx;
     const BvhNode *bvh_nodes;
     const BvhObj *bvh_objs;
+    const BvhNode *bvh_cores;  // core twins of bvh_nodes (walk32 only)
     const double *ray;    // [6][njobs] primary rays of the chunk (raygen_kernel)
     const unsigned long long *ray_rng;  // [njobs] stream state after the camera draws
     const uint16_t *ray_ndraw;          // [njobs] draws used by ray generation; 0xffff = pixel outside the frame

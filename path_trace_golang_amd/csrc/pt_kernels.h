@@ -58,6 +58,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the p
 #ifndef PT_BVH_WAVES
 #define PT_BVH_WAVES 4  // blocks of 256 threads per CU (= waves per SIMD) the BVH kernels are compiled for
 #endif
+#ifndef PT_FLAT_WAVES
+#define PT_FLAT_WAVES 5  // waves per SIMD the flat-scan trace kernels and glass_kernel are compiled for (A/B builds: -DPT_FLAT_WAVES=4|6)
+#endif
 #define PT_HOLE 0xffffffffu     // job id of a reserved but unused queue slot
 // The host sizes every path-state queue as (entries a pass can append) + (waves of the widest writer grid) x (the larger
 // window): queue_slack() in ptcore.hip.  What that arithmetic relies on:
@@ -411,6 +414,61 @@ __device__ __forceinline__ bool wins(int mode, bool is_box, int i, double t, int
     return best_is_box || i > best;
 }
 
+// The closest hit / exit search of ONE ray by the whole wave: lane l tests objects l, l + 64, ... of the world (every object,
+// the reference's FP64 tests), then the lanes' winners are merged by `wins`, the order-free statement of the sequential loop
+// (valid for a ray whose every t is a number: the callers' `tame` rays).  For the rays no hierarchy helps with: a ray from so
+// far away that the reference's own sphere discriminant cancels (clip_ray: `far`) must keep every object within `infl` of
+// its line, and when that tube is as wide as the scene a per-lane walk degenerates into one lane testing every object alone --
+// ONE such ray in a frame of 2 * 10^8 took 100 ms at 10^5 objects (profiles/r03_fat_ray.txt).  Here it costs
+// nobj / 64 tests per lane.  All 64 lanes must call this together (wave-uniform ray and mode).
+// (Not inlined: inside the persistent loop its registers cost the BVH kernel 27 more spilled VGPRs; as a function the loop
+// only pays the call sequence on the rare path.)
+struct LinearHit {
+    int best;
+    double tmax;
+};
+__device__ __attribute__((noinline)) LinearHit scan_linear_wave(int nobj, const DevObj *__restrict__ objs, double rox, double roy, double roz, double rdx,
+                                                                double rdy, double rdz, int mode, uint32_t lane) {
+    const RayD r{rox, roy, roz, rdx, rdy, rdz};
+    int best;
+    double tmax;
+    const double tmin = mode ? 0.0001 : 0.001;
+    tmax = ptm::max_float64();
+    best = -1;
+    bool best_is_box = false;
+    const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+    const double ivx = 1 / r.dx, ivy = 1 / r.dy, ivz = 1 / r.dz;
+    for (int i = (int)lane; i < nobj; i += PT_WAVE) {
+        const DevObj &o = objs[i];
+        const int kind = o.kind & 0xff;
+        if (mode != 0 && !(o.kind & 0x100)) continue;  // only glass can end an exit search (renderer.go:333)
+        double t = 0;
+        bool valid;
+        const bool is_box = kind == KIND_BOX;
+        if (kind == KIND_SPHERE) valid = sphere_exact(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, tmin, tmax, t);
+        else if (is_box) valid = box_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t);
+        else valid = plane_exact(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, tmin, tmax, t);
+        if (valid && wins(mode, is_box, i, t, best, best_is_box, tmax) && (mode == 0 || exit_candidate_ok(o, kind, r, t))) {
+            best = i;
+            tmax = t;
+            best_is_box = is_box;
+        }
+    }
+    // merge: after six exchanges every lane holds the wave's winner
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ob = __shfl_xor(best, off, 64);
+        const double ot = __shfl_xor(tmax, off, 64);
+        const int obox = __shfl_xor((int)best_is_box, off, 64);
+        if (ob >= 0 && wins(mode, obox != 0, ob, ot, best, best_is_box, tmax)) {
+            best = ob;
+            tmax = ot;
+            best_is_box = obox != 0;
+        }
+    }
+    return LinearHit{best, tmax};
+}
+
 // The record lists one bitmask scan runs over: every finite object (closest-hit scans, and exit searches of the
 // all-in-one kernel, which mask the dielectric ones) or the dielectric objects only (exit searches of glass_kernel).
 template <typename SphPtr, typename BoxPtr>
@@ -691,6 +749,30 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
     }
 }
 
+// A node as the FP32 walk uses it: the slot boxes as centre and half extent, two slots per register pair (seven 16-byte loads).
+struct NodeQ {
+    v2f cA[3], cB[3], hA[3], hB[3];  // [axis]: slots (0, 1) and (2, 3)
+    int nbase, obase;
+    uint32_t meta;
+};
+__device__ __forceinline__ NodeQ load_node(const BvhNode *__restrict__ p) {
+    const float4 *p4 = reinterpret_cast<const float4 *>(p);
+    NodeQ n;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float4 c = p4[k], h = p4[3 + k];
+        n.cA[k] = v2f{c.x, c.y};
+        n.cB[k] = v2f{c.z, c.w};
+        n.hA[k] = v2f{h.x, h.y};
+        n.hB[k] = v2f{h.z, h.w};
+    }
+    const int4 m4 = reinterpret_cast<const int4 *>(p)[6];
+    n.nbase = m4.x;
+    n.obase = m4.y;
+    n.meta = (uint32_t)m4.z;
+    return n;
+}
+
 // True when the FP32 quantities scan_bvh derives from the ray are inside the range its bounds were analysed
 // for (direction length and re-based origin); a little stricter than the FP32 test of the careful
 // instantiation, so a wave that passes here needs no per-node check.
@@ -799,6 +881,9 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
         const int walking = __popcll(__ballot(cur >= 0));
         const bool waiting = __ballot(pend != 0) != 0;
         // stragglers carry on in the next trip (with no test pending: what waits is tested before the loop is left)
+        // (Ending a trip after a fixed number of visits instead -- so that lanes that finish early wait for a bounded time -- was
+        // measured in round 3 and lost: 8 / 12 / 16 / 24 / 32 visits per trip 80.9 / 71.0 / 67.0 / 63.8 / 62.6 ms against 62.7 at 10^5
+        // objects, profiles/r03_visits_sweep.txt: every trip pays the set-up, shading and refill code for the whole wave.)
         const bool leaving = walking < F.bvh_min_lanes && walking < n_start;
         if (!waiting && (walking == 0 || leaving)) break;
         // ---- walk internal nodes: a lane that reaches a node with pierced object slots waits (pend != 0) for the exact
@@ -859,7 +944,7 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 t0[0] = t0[1] = t0[2] = t0[3] = 0.0f;
             }
             const uint32_t meta = nd.meta;
-            const uint32_t oh = hb & (meta >> 12);  // object children pierced (hb has only bits 0-3)
+            const uint32_t oh = hb & (meta >> 12) & 0xfu;  // object children pierced
             // internal children nearest first: sort keys = entry parameter (>= 0, so its bits order like the
             // value) with 2*slot in the low three bits; 0xffffffff = not a candidate
             uint32_t k0, k1, k2, k3;
@@ -868,9 +953,8 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const uint32_t bits = (__float_as_uint(t0[s]) & ~7u) | (uint32_t)(2 * s);
-                    // sign-extended one-bit field: all ones when slot s is NOT an internal node (meta bits 16-19)
-                    const uint32_t not_internal = (uint32_t)__builtin_amdgcn_sbfe((int)meta, 16 + s, 1);
-                    key[s] = ((hb & (1u << s)) ? bits : 0xffffffffu) | not_internal;
+                    // a candidate only when the slot is pierced AND an internal node (meta bits 8-11)
+                    key[s] = ((hb & (meta >> 8)) & (1u << s)) ? bits : 0xffffffffu;
                 }
                 // 5-exchange network
                 uint32_t a0 = key[0] < key[1] ? key[0] : key[1], a1 = key[0] < key[1] ? key[1] : key[0];
@@ -1399,7 +1483,7 @@ __device__ __forceinline__ P pt_launder(P p) {
 // and no lane spends a whole trip through the scan on an exit search.
 // (launch bounds: the flat scans are asked to fit five waves per SIMD = 96 VGPRs, the BVH forms four = 128; the diagnostic form is not held to anything)
 template <bool STATS, bool PROF, int SCAN, bool SPLIT>
-__global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? PT_BVH_WAVES : 5) void trace_kernel(const TraceArgs A) {
+__global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? PT_BVH_WAVES : PT_FLAT_WAVES) void trace_kernel(const TraceArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevFrame &F = A.F;
     const TraceBuffers &B = A.B;  // set-up and epilogue only; the loop reads the argument block through KA
@@ -1608,6 +1692,7 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == S
         int best = -1;
         double tmax = 0;
         bool scanned = true;  // false: this lane's BVH walk goes on in the next trip, nothing to shade yet
+        bool fat = false;     // BVH path: a far-away ray whose widened bounds would take in a sixteenth of the scene or more
         if (active) {
             // -------------------------------------------------------- scan
             SEC_BEGIN(SEC_SCAN)
@@ -1637,6 +1722,8 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == S
                         scan_broad_narrow_wide<PROF, VERIFY, SPLIT ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
                     else if (BITMASK)
                         scan_broad_narrow<PROF, VERIFY, SPLIT ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
+                    else if ((fat = !trav.live && clip.far && !clip.miss && clip.infl * 16.0 > F.scene_bound))
+                        scanned = false;  // no walk for this one: the whole wave scans the world for it, below
                     else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
                         scanned = scan_bvh<PROF, true>(F, g_obj, g_pl, bvh_nodes_, lds_nodes, bvh_objs_, lds_stack + threadIdx.x,
                                                        ray, clip, mode, trav, best, tmax, ph);
@@ -1663,6 +1750,21 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == S
                 }
             }
             SEC_END(SEC_SCAN)
+        }
+        if (BIG) {  // vanishingly rare (one ray in 2 * 10^8 on the synthetic scenes): usually all this costs is the ballot
+            uint64_t fm = __ballot(fat);
+            while (fm != 0) {
+                const int src = __ffsll((long long)fm) - 1;
+                fm &= fm - 1;
+                const LinearHit fh = scan_linear_wave(F.nobj, KA->B.objs, __shfl(ox, src, 64), __shfl(oy, src, 64), __shfl(oz, src, 64), __shfl(dx, src, 64),
+                                                      __shfl(dy, src, 64), __shfl(dz, src, 64), __shfl(mode, src, 64), lane);
+                if ((int)lane == src) {
+                    best = fh.best;
+                    tmax = fh.tmax;
+                    scanned = true;
+                }
+                if (lane == 0) atomicAdd(KA->B.counters + 23, 1ull);
+            }
         }
         if (active && scanned) {
             // -------------------------------------------------------- shade
@@ -1831,7 +1933,7 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == S
 // VERIFY: the exit search is also done by the plain object-by-object loop and disagreements are counted.
 // WIDE: more than 32 spheres or boxes in the scene: the exit search takes its (dielectric-only) records in groups of 32.
 template <bool STATS, bool VERIFY, bool WIDE>
-__global__ __launch_bounds__(PT_BLOCK, 5) void glass_kernel(const DevFrame F, const TraceBuffers B) {
+__global__ __launch_bounds__(PT_BLOCK, PT_FLAT_WAVES) void glass_kernel(const DevFrame F, const TraceBuffers B) {
     extern __shared__ __align__(16) unsigned char smem[];
     DevObj *lds_obj = reinterpret_cast<DevObj *>(smem);
     DevMat *lds_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));

@@ -296,6 +296,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BVH_WAVES) void wf_traverse_kernel(con
         int best = -1;
         double tmax = 0;
         bool scanned = true;
+        bool fat = false;  // a far-away ray with bounds as wide as the scene: the whole wave scans the world for it (see trace_kernel)
         if (have) {
             const RayD ray{ox, oy, oz, dx, dy, dz};
             const double a_ = dx * dx + dy * dy + dz * dz;
@@ -306,7 +307,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BVH_WAVES) void wf_traverse_kernel(con
                 scan_uniform(F, g_obj, ray, MODE, best, tmax);
                 trav.live = false;
             } else {
-                if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
+                if ((fat = !trav.live && clip.far && !clip.miss && clip.infl * 16.0 > F.scene_bound))
+                    scanned = false;
+                else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
                     scanned = scan_bvh<false, true>(F, g_obj, g_pl, B.bvh_nodes, lds_nodes, B.bvh_objs, lds_stack + threadIdx.x, ray, clip, MODE,
                                                     trav, best, tmax, ph);
                 else
@@ -329,6 +332,21 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BVH_WAVES) void wf_traverse_kernel(con
                     best = best2;
                     tmax = tmax2;
                 }
+            }
+        }
+        {
+            uint64_t fm = __ballot(fat);
+            while (fm != 0) {
+                const int src = __ffsll((long long)fm) - 1;
+                fm &= fm - 1;
+                const LinearHit fh = scan_linear_wave(F.nobj, B.objs, __shfl(ox, src, 64), __shfl(oy, src, 64), __shfl(oz, src, 64), __shfl(dx, src, 64),
+                                                      __shfl(dy, src, 64), __shfl(dz, src, 64), MODE, lane);
+                if ((int)lane == src) {
+                    best = fh.best;
+                    tmax = fh.tmax;
+                    scanned = true;
+                }
+                if (lane == 0) atomicAdd(B.counters + 23, 1ull);
             }
         }
         if (have && scanned) {

@@ -26,6 +26,7 @@
 #include "pt_device.h"
 #include "pt_kernels.h"
 #include "pt_wavefront.h"
+#include "pt_walk32.h"
 #include "pt_math.h"
 
 using namespace ptd;
@@ -87,6 +88,7 @@ struct Device {
     size_t bytes_cap = 0;             // bytes of per-pass buffers (jobs + path-state queues) that fitted after an allocation failed (0: never failed)
     DevBuf<BvhNode> bvh_nodes;
     DevBuf<BvhObj> bvh_objs;
+    DevBuf<BvhNode> bvh_cores;
     DevBuf<double> L;
     DevBuf<double> ray;
     DevBuf<unsigned long long> ray_rng;
@@ -108,6 +110,8 @@ struct Device {
     DevBuf<unsigned long long> xq_rs;
     DevBuf<uint32_t> xq_u32;
     int blocks_per_cu_wf = 0;
+    int blocks_per_cu_walk = 0;        // wf_walk32_kernel (PTCORE_PIPELINE=walk32)
+    DevBuf<uint32_t> cand_ids, cand_n, slow_list;  // walk32: candidate lists of the running level, entries left to the FP64 traversal
     DevBuf<uint32_t> wf_perm, wf_key, wf_bins;  // ray sorting of the wavefront form
     size_t q_cap = 0;
     DevBuf<unsigned long long> counters;
@@ -140,6 +144,7 @@ struct Frame {
     size_t lds_bytes = 0;
     size_t glass_lds_bytes = 0;
     bool wavefront = false;  // the wavefront form (pt_wavefront.h) instead of the all-in-one loop
+    bool walk32 = false;     // ... with its traversal pass split into the FP32 walk and the exact pass of pt_walk32.h
     size_t shade_lds_bytes = 0;
     int split_rounds = 0;  // trace + glass pass pairs before the all-in-one pass (0: all-in-one only)
     bool has_glass = false;  // some object is dielectric
@@ -165,6 +170,7 @@ struct SceneData {
     std::vector<int32_t> plane_idx;
     std::vector<BvhNode> bvh_nodes;
     std::vector<BvhObj> bvh_objs;
+    std::vector<BvhNode> bvh_cores;   // core twins of bvh_nodes (the FP32 walk's certain bounds)
     int bvh_depth = 0;
     int bvh_stack_need = 0;
     bool has_glass = false;           // some object is dielectric
@@ -188,7 +194,7 @@ struct pt_ctx {
     DevBuf<double> f_accum;
     DevBuf<uint32_t> f_seg, f_draw;
     size_t l_budget_bytes = (size_t)48 << 30;  // per-chunk job buffers (radiance, primary rays, path-state queues): a sixth of the 288 GB
-    int pipeline = -1;     // PTCORE_PIPELINE=mega|wavefront (default: the all-in-one loop)
+    int pipeline = -1;     // PTCORE_PIPELINE=mega|wavefront|walk32 (default: by scene, see frame_open)
     int wf_min_lanes = 40; // PTCORE_WF_MIN_LANES: the walk loop of a traversal pass is left for a refill below this many walking lanes
     int wf_sort = 0;       // PTCORE_WF_SORT=1: reorder the paths of a level by direction octant and origin cell
     int split_rounds = 2;  // PTCORE_SPLIT_ROUNDS: trace + glass pass pairs per chunk before the all-in-one pass (bitmask scan only)
@@ -522,6 +528,8 @@ int32_t dev_events(Device &d, std::vector<EventPair> &v, size_t need) {
 
 #define PT_GLASS_MAX_BLOCKS_PER_CU 8
 
+size_t walk32_lds_bytes() { return 0; }  // the stacks are static LDS of the kernel
+
 // Slots a path-state queue needs beyond one per job of the pass: every wave of a pass that appends to it reserves slots in
 // windows (one atomic per window, see trace_kernel) and may leave its last window partly empty -- fewer than one window per
 // wave and pass.  Derived from the very grids the launches use (dev_step, dev_step_wavefront), none of which is wider
@@ -593,12 +601,15 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
             HIP_TRY(hipMemcpyAsync(d.bvh_nodes.p, sd.bvh_nodes.data(), sd.bvh_nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, d.stream));
         if (!sd.bvh_objs.empty())
             HIP_TRY(hipMemcpyAsync(d.bvh_objs.p, sd.bvh_objs.data(), sd.bvh_objs.size() * sizeof(BvhObj), hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(d.bvh_cores.reserve(std::max<size_t>(1, sd.bvh_cores.size())));
+        if (!sd.bvh_cores.empty())
+            HIP_TRY(hipMemcpyAsync(d.bvh_cores.p, sd.bvh_cores.data(), sd.bvh_cores.size() * sizeof(BvhNode), hipMemcpyHostToDevice, d.stream));
         HIP_TRY(hipStreamSynchronize(d.stream));
         d.scene_gen = sd.gen;
     }
     HIP_TRY(d.queue.reserve(8));
-    HIP_TRY(d.counters.reserve(24));
-    HIP_TRY(hipMemsetAsync(d.counters.p, 0, 24 * sizeof(unsigned long long), d.stream));
+    HIP_TRY(d.counters.reserve(48));
+    HIP_TRY(hipMemsetAsync(d.counters.p, 0, 48 * sizeof(unsigned long long), d.stream));
     if (ctx->profile_sections) {
         HIP_TRY(d.prof.reserve(3 * ptk::SEC_COUNT));
         HIP_TRY(hipMemsetAsync(d.prof.p, 0, 3 * ptk::SEC_COUNT * sizeof(unsigned long long), d.stream));
@@ -625,6 +636,11 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         if (bvh) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::wf_traverse_kernel<0, false>, PT_BLOCK, lds));
         else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::wf_scan_flat_kernel<0, false>, PT_BLOCK, lds));
         d.blocks_per_cu_wf = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
+        if (fr.walk32) {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ptk::wf_walk32_kernel<0>, PT_BLOCK, walk32_lds_bytes()));
+            d.blocks_per_cu_walk = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
+            if (std::getenv("PTCORE_VERBOSE")) std::fprintf(stderr, "ptcore: walk32: %d blocks per CU for the FP32 walk, %d for the FP64 traversal of the slow list\n", d.blocks_per_cu_walk, d.blocks_per_cu_wf);
+        }
     }
     if (fr.split_rounds > 0) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, true), PT_BLOCK, lds));
@@ -643,12 +659,13 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
     auto queue_cap = [&](size_t njobs_max) { return njobs_max + queue_slack(ctx, d, njobs_max); };
     auto need_bytes = [&](uint32_t chunk) {
         const size_t nj = (size_t)ns * chunk;
-        return nj * job_bytes + nqueues * queue_cap(nj) * qentry + (fr.wavefront && ctx->wf_sort ? 2 * queue_cap(nj) * sizeof(uint32_t) : 0);
+        return nj * job_bytes + nqueues * queue_cap(nj) * qentry + (fr.wavefront && ctx->wf_sort ? 2 * queue_cap(nj) * sizeof(uint32_t) : 0) +
+               (fr.walk32 ? (PT_CAND_MAX + 2) * queue_cap(nj) * sizeof(uint32_t) : 0);
     };
     auto held_bytes = [&]() {
         return d.L.cap * sizeof(double) + d.ray.cap * sizeof(double) + d.ray_rng.cap * 8 + d.ray_ndraw.cap * 2 + (d.job_seg.cap + d.job_draw.cap) * 4 +
                (d.gq_d.cap + d.cq_d.cap + d.xq_d.cap) * sizeof(double) + (d.gq_rs.cap + d.cq_rs.cap + d.xq_rs.cap) * 8 +
-               (d.gq_u32.cap + d.cq_u32.cap + d.xq_u32.cap + d.wf_perm.cap + d.wf_key.cap) * 4;
+               (d.gq_u32.cap + d.cq_u32.cap + d.xq_u32.cap + d.wf_perm.cap + d.wf_key.cap + d.cand_ids.cap + d.cand_n.cap + d.slow_list.cap) * 4;
     };
     // The budget covers everything a pass holds, the window slack of the queues included: when the queues push the total over it,
     // the samples per pass shrink (a frame is cut into more passes; pixels do not depend on that).
@@ -700,6 +717,11 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
                     if (e == hipSuccess) e = d.wf_key.reserve(qcap);
                     if (e == hipSuccess) e = d.wf_bins.reserve(PT_WF_BINS + 8);
                 }
+                if (fr.walk32) {
+                    if (e == hipSuccess) e = d.cand_ids.reserve((size_t)PT_CAND_MAX * qcap);
+                    if (e == hipSuccess) e = d.cand_n.reserve(qcap);
+                    if (e == hipSuccess) e = d.slow_list.reserve(qcap);
+                }
             }
             d.q_cap = qcap;
         }
@@ -709,6 +731,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         d.L.release(); d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release(); d.job_seg.release(); d.job_draw.release();
         d.gq_d.release(); d.cq_d.release(); d.gq_rs.release(); d.cq_rs.release(); d.gq_u32.release(); d.cq_u32.release();
         d.xq_d.release(); d.xq_rs.release(); d.xq_u32.release(); d.wf_perm.release(); d.wf_key.release();
+        d.cand_ids.release(); d.cand_n.release(); d.slow_list.release();
         fr.chunk = std::max<uint32_t>(1, fr.chunk / 2);
         d.bytes_cap = need_bytes(fr.chunk);
         if (std::getenv("PTCORE_VERBOSE")) std::fprintf(stderr, "ptcore: device %d is short of memory, samples per pass reduced to %u\n", d.ordinal, fr.chunk);
@@ -758,7 +781,7 @@ int32_t dev_step_wavefront(pt_ctx *ctx, Device &d, const DevFrame &F, const Trac
     // together leave at most 2 x grid_pass x 4 waves x PT_CONT_BLOCK slots empty, which is what queue_slack() allocates.
     const uint32_t grid_pass = std::max(1u, std::min((uint32_t)(d.num_cu * PT_WF_PASS_BLOCKS_PER_CU), blocks_all));
     const int levels = std::max(0, fr.cfg.max_depth);
-    if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + 2 * (size_t)levels + 1)) return rc;
+    if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + 4 * (size_t)levels + 1)) return rc;
     if (int32_t rc = dev_events(d, d.ev_glass, d.n_glass + 3 * (size_t)levels + 2)) return rc;
     auto timed = [&](std::vector<EventPair> &v, size_t &n, auto &&launch) -> int32_t {
         EventPair &e = v[n++];
@@ -768,10 +791,52 @@ int32_t dev_step_wavefront(pt_ctx *ctx, Device &d, const DevFrame &F, const Trac
         HIP_TRY(hipEventRecord(e.b, d.stream));
         return PT_OK;
     };
+    // walk32 (pt_walk32.h): the FP32 walk lists candidates, the FP64 traversal answers the few entries the walk hands over
+    const bool walk32 = fr.walk32 && bvh;
+    const bool walk_diag = std::getenv("PTCORE_WALK_STATS") != nullptr;
+    auto walk_args = [&]() {
+        ptk::Walk32Args K;
+        std::memset(&K, 0, sizeof K);
+        K.W = A;
+        K.cand_ids = d.cand_ids.p;
+        K.cand_n = d.cand_n.p;
+        K.slow_list = d.slow_list.p;
+        K.slow_count = qw + 6;
+        K.cores = d.bvh_cores.p;
+        K.min_lanes = ctx->wf_min_lanes;
+        K.diag = d.counters.p + 24;
+        return K;
+    };
+    const uint32_t grid_walk = std::max(1u, std::min((uint32_t)(d.num_cu * std::max(1, d.blocks_per_cu_walk)), blocks_all));
     auto scan_pass = [&](int mode) -> int32_t {
         HIP_TRY(hipMemsetAsync(qw, 0, sizeof(unsigned int), d.stream));
         if (d.trace_is_split.size() <= d.n_trace) d.trace_is_split.resize(d.n_trace + 1);
         d.trace_is_split[d.n_trace] = 0;
+        if (walk32) {
+            HIP_TRY(hipMemsetAsync(qw + 6, 0, sizeof(unsigned int), d.stream));
+            const ptk::Walk32Args K = walk_args();
+            if (int32_t rc = timed(d.ev_trace, d.n_trace, [&] {
+                    if (walk_diag) {
+                        if (mode == 0) hipLaunchKernelGGL((ptk::wf_walk32_kernel<0, true>), dim3(grid_walk), dim3(PT_BLOCK), walk32_lds_bytes(), d.stream, K);
+                        else hipLaunchKernelGGL((ptk::wf_walk32_kernel<1, true>), dim3(grid_walk), dim3(PT_BLOCK), walk32_lds_bytes(), d.stream, K);
+                    } else if (mode == 0) hipLaunchKernelGGL((ptk::wf_walk32_kernel<0>), dim3(grid_walk), dim3(PT_BLOCK), walk32_lds_bytes(), d.stream, K);
+                    else hipLaunchKernelGGL((ptk::wf_walk32_kernel<1>), dim3(grid_walk), dim3(PT_BLOCK), walk32_lds_bytes(), d.stream, K);
+                }))
+                return rc;
+            // the entries the walk handed over, through the FP64 traversal (their number lives on the device)
+            HIP_TRY(hipMemsetAsync(qw, 0, sizeof(unsigned int), d.stream));
+            if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + 1)) return rc;
+            if (d.trace_is_split.size() <= d.n_trace) d.trace_is_split.resize(d.n_trace + 1);
+            d.trace_is_split[d.n_trace] = 0;
+            ptk::WfArgs S = A;
+            S.perm = d.slow_list.p;
+            S.n_sorted = qw + 6;
+            const uint32_t grid_slow = std::max(1u, std::min(grid_scan, (uint32_t)d.num_cu));
+            return timed(d.ev_trace, d.n_trace, [&] {
+                if (mode == 0) hipLaunchKernelGGL((ptk::wf_traverse_kernel<0, false>), dim3(grid_slow), dim3(PT_BLOCK), lds_scan, d.stream, S);
+                else hipLaunchKernelGGL((ptk::wf_traverse_kernel<1, false>), dim3(grid_slow), dim3(PT_BLOCK), lds_scan, d.stream, S);
+            });
+        }
         return timed(d.ev_trace, d.n_trace, [&] {
             if (bvh) {
                 if (mode == 0) {
@@ -827,7 +892,16 @@ int32_t dev_step_wavefront(pt_ctx *ctx, Device &d, const DevFrame &F, const Trac
         HIP_TRY(hipMemsetAsync(cur_out.count, 0, sizeof(unsigned int), d.stream));
         HIP_TRY(hipMemsetAsync(qe.count, 0, sizeof(unsigned int), d.stream));
         if (int32_t rc = timed(d.ev_glass, d.n_glass, [&] {
-                if (stats) hipLaunchKernelGGL(ptk::wf_shade_kernel<true>, dim3(grid_pass), dim3(PT_BLOCK), lds_shade, d.stream, A);
+                if (walk32) {
+                    const ptk::Walk32Args K = walk_args();
+                    if (stats) {
+                        if (verify) hipLaunchKernelGGL((ptk::wf_shade32_kernel<true, true>), dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, K);
+                        else hipLaunchKernelGGL((ptk::wf_shade32_kernel<true, false>), dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, K);
+                    } else {
+                        if (verify) hipLaunchKernelGGL((ptk::wf_shade32_kernel<false, true>), dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, K);
+                        else hipLaunchKernelGGL((ptk::wf_shade32_kernel<false, false>), dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, K);
+                    }
+                } else if (stats) hipLaunchKernelGGL(ptk::wf_shade_kernel<true>, dim3(grid_pass), dim3(PT_BLOCK), lds_shade, d.stream, A);
                 else hipLaunchKernelGGL(ptk::wf_shade_kernel<false>, dim3(grid_pass), dim3(PT_BLOCK), lds_shade, d.stream, A);
             }))
             return rc;
@@ -835,7 +909,16 @@ int32_t dev_step_wavefront(pt_ctx *ctx, Device &d, const DevFrame &F, const Trac
             A.qin = qe;
             if (int32_t rc = scan_pass(1)) return rc;
             if (int32_t rc = timed(d.ev_glass, d.n_glass, [&] {
-                    if (stats) hipLaunchKernelGGL(ptk::wf_exit_kernel<true>, dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, A);
+                    if (walk32) {
+                        const ptk::Walk32Args K = walk_args();
+                        if (stats) {
+                            if (verify) hipLaunchKernelGGL((ptk::wf_exit32_kernel<true, true>), dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, K);
+                            else hipLaunchKernelGGL((ptk::wf_exit32_kernel<true, false>), dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, K);
+                        } else {
+                            if (verify) hipLaunchKernelGGL((ptk::wf_exit32_kernel<false, true>), dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, K);
+                            else hipLaunchKernelGGL((ptk::wf_exit32_kernel<false, false>), dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, K);
+                        }
+                    } else if (stats) hipLaunchKernelGGL(ptk::wf_exit_kernel<true>, dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, A);
                     else hipLaunchKernelGGL(ptk::wf_exit_kernel<false>, dim3(grid_pass), dim3(PT_BLOCK), lds_mat, d.stream, A);
                 }))
                 return rc;
@@ -879,6 +962,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     B.plane_idx = d.plane_idx.p;
     B.bvh_nodes = d.bvh_nodes.p;
     B.bvh_objs = d.bvh_objs.p;
+    B.bvh_cores = d.bvh_cores.p;
     B.L = d.L.p;
     B.ray = d.ray.p;
     B.ray_rng = d.ray_rng.p;
@@ -940,6 +1024,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
         if (fr.wavefront) {
             if (int32_t rc = dev_step_wavefront(ctx, d, F, B)) return rc;
         } else {
+        const bool pass_log = std::getenv("PTCORE_DEBUG_PASS_LOG") != nullptr;
         auto launch_trace = [&](bool split, bool first) -> int32_t {
             TraceArgs A;
             A.F = F;
@@ -957,6 +1042,18 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
             hipLaunchKernelGGL(pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, split), dim3(grid), dim3(PT_BLOCK), lds, d.stream, A);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(e.b, d.stream));
+            if (pass_log) {  // PTCORE_DEBUG_PASS_LOG=1 (diagnostics): what every trace pass did; serialises the stream
+                HIP_TRY(hipStreamSynchronize(d.stream));
+                unsigned long long c[24];
+                HIP_TRY(hipMemcpy(c, d.counters.p, sizeof c, hipMemcpyDeviceToHost));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+                static unsigned long long prev[24] = {};
+                std::fprintf(stderr, "ptcore pass: %s grid %u  %.3f ms  segments +%llu  exit scans +%llu  parked +%llu  ended here +%llu  continuations in +%llu  -> %.1f Mseg/s\n",
+                             split ? "trace<split>" : "trace<all-in-one>", grid, ms, c[0] - prev[0], c[1] - prev[1], c[5] - prev[5], c[18] - prev[18],
+                             c[7] - prev[7], (double)(c[0] - prev[0]) / (ms * 1e3));
+                std::memcpy(prev, c, sizeof prev);
+            }
             return PT_OK;
         };
         if (rounds == 0) {
@@ -1056,10 +1153,19 @@ int32_t dev_collect(Device &d, pt_stats *st, int slot) {
     HIP_TRY(hipSetDevice(d.ordinal));
     HIP_TRY(hipStreamSynchronize(d.stream));
     if (d.nlocal == 0) return PT_OK;
-    unsigned long long c[24] = {};
+    unsigned long long c[48] = {};
     HIP_TRY(hipMemcpy(c, d.counters.p, sizeof c, hipMemcpyDeviceToHost));
+    if (std::getenv("PTCORE_WALK_STATS") && c[24 + 2])
+        std::fprintf(stderr, "ptcore walk32: rays walked %llu (+%llu missing the scene cube, %llu handed over before the walk, %llu of them far AND through the cube, widest inflation %llu margins), "
+                             "node visits %llu, core visits %llu, wave iterations %llu (%.1f lanes per iteration), refills %llu, candidates %llu, handed over for > %d candidates %llu, for stack depth %llu\n",
+                     c[24 + 8], c[24 + 9], c[24 + 5], c[24 + 10], c[24 + 11], c[24 + 0], c[24 + 1], c[24 + 2], (double)(c[24] + c[25]) / (double)c[24 + 2], c[24 + 3], c[24 + 4], PT_CAND_MAX,
+                     c[24 + 6], c[24 + 7]);
     if (c[19]) return fail(PT_ERR_STATE, "internal: a path-state queue overflowed (" + std::to_string(c[19]) + " paths lost); the frame is invalid");
     g_mismatches += c[4];
+    if ((c[20] || c[21] || c[23]) && std::getenv("PTCORE_VERBOSE"))
+        std::fprintf(stderr, "ptcore: BVH path: %llu wave-trips through the plain every-object scan (rays with non-finite or absurd components), "
+                             "%llu through the careful traversal (far-away rays), %llu lane-trips with bounds the FP32 tests were not analysed for, "
+                             "%llu rays scanned by a whole wave (bounds as wide as the scene)\n", c[20], c[21], c[22], c[23]);
     if (c[4]) std::memcpy(g_mismatch_sample, c + 8, sizeof g_mismatch_sample);
     st->segments += c[0];
     st->exit_scans += c[1];
@@ -1167,6 +1273,7 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     const bool big = scan == ptk::SCAN_BVH || scan == ptk::SCAN_VERIFY_BVH;
     sd.bvh_nodes.clear();
     sd.bvh_objs.clear();
+    sd.bvh_cores.clear();
     F.bvh_root = F.bvh_root_exit = -1;
     const std::vector<DevObj> &w = sd.world;
     if (big) {
@@ -1195,6 +1302,13 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
         sd.bvh_stack_need = std::max(built.stack_need, builtd.stack_need);
         if (sd.bvh_stack_need >= PT_BVH_STACK)
             return fail(PT_ERR_INVALID, "BVH deeper than the traversal stack");
+        // core twins (the FP32 walk of pt_walk32.h): inside-the-object boxes of the main tree's object slots; the dielectric
+        // tree's twins are empty (an exit search takes no FP32 bound)
+        sd.bvh_cores = ptbvh::build_cores(built, w, margin);
+        sd.bvh_cores.resize(built.nodes.size() + builtd.nodes.size());
+        for (size_t q = built.nodes.size(); q < sd.bvh_cores.size(); q++) {
+            std::memset(&sd.bvh_cores[q], 0, sizeof(BvhNode));
+        }
         const int32_t node_off = (int32_t)built.nodes.size(), obj_off = (int32_t)built.order.size();
         F.bvh_main_nodes = node_off;
         sd.bvh_nodes = std::move(built.nodes);
@@ -1274,7 +1388,8 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
        // Measured slower than the all-in-one loop in every regime, so it is the A/B, not the default.
         const bool bvh = sd.scan == ptk::SCAN_BVH || sd.scan == ptk::SCAN_VERIFY_BVH;
         const bool flat = sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY;
-        fr.wavefront = !ctx->profile_sections && ctx->pipeline == 1 && (bvh || flat);
+        fr.wavefront = !ctx->profile_sections && ((ctx->pipeline == 1 && (bvh || flat)) || (ctx->pipeline == 2 && bvh));
+        fr.walk32 = fr.wavefront && ctx->pipeline == 2;
         if (fr.wavefront) fr.split_rounds = 0;
         fr.shade_lds_bytes = (size_t)sd.Fs.nmat * sizeof(DevMat) + (sd.Fs.world_in_lds ? (size_t)sd.Fs.nobj * sizeof(DevObj) : 0);
     }
@@ -1298,7 +1413,7 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     uint32_t chunk = cfg->spp_chunk > 0 ? (uint32_t)cfg->spp_chunk : 0;
     const uint32_t slots = std::max(1u, max_slots);
     // per job: 32 B radiance record + 58 B primary ray, and with split passes two path-state queues of 100 B per entry
-    const size_t job_bytes = 90 + (fr.wavefront ? 330 : fr.split_rounds > 0 && fr.has_glass ? 220 : 0);
+    const size_t job_bytes = 90 + (fr.wavefront ? 330 + (fr.walk32 ? 4 * (PT_CAND_MAX + 2) : 0) : fr.split_rounds > 0 && fr.has_glass ? 220 : 0);
     if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * job_bytes));
     chunk = std::min<uint32_t>(chunk, (uint32_t)std::max(1, cfg->samples_per_px));
     chunk = std::min<uint32_t>(chunk, std::max(1u, 0x7fffffffu / slots));
@@ -1361,7 +1476,7 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
     }
     if (const char *e = std::getenv("PTCORE_PROFILE")) ctx->profile_sections = std::atoi(e) != 0;
     if (const char *e = std::getenv("PTCORE_SPLIT_ROUNDS")) ctx->split_rounds = std::max(0, std::min(64, std::atoi(e)));
-    if (const char *e = std::getenv("PTCORE_PIPELINE")) ctx->pipeline = !std::strcmp(e, "wavefront") ? 1 : !std::strcmp(e, "mega") ? 0 : -1;
+    if (const char *e = std::getenv("PTCORE_PIPELINE")) ctx->pipeline = !std::strcmp(e, "wavefront") ? 1 : !std::strcmp(e, "walk32") ? 2 : !std::strcmp(e, "mega") ? 0 : -1;
     if (const char *e = std::getenv("PTCORE_WF_MIN_LANES")) ctx->wf_min_lanes = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("PTCORE_WF_SORT")) ctx->wf_sort = std::atoi(e);
     if (const char *e = std::getenv("PTCORE_BLOCKS_PER_CU")) {
@@ -1408,12 +1523,13 @@ void pt_destroy(pt_ctx *ctx) {
         if (hipSetDevice(d.ordinal) != hipSuccess) continue;
         if (d.own_stream) (void)hipStreamSynchronize(d.own_stream);
         d.ray.release(); d.ray_rng.release(); d.ray_ndraw.release();
-        d.objs.release(); d.mats.release(); d.bsph.release(); d.bbox.release(); d.plane_idx.release(); d.bvh_nodes.release(); d.bvh_objs.release(); d.L.release(); d.job_seg.release(); d.job_draw.release();
+        d.objs.release(); d.mats.release(); d.bsph.release(); d.bbox.release(); d.plane_idx.release(); d.bvh_nodes.release(); d.bvh_objs.release(); d.bvh_cores.release(); d.L.release(); d.job_seg.release(); d.job_draw.release();
         d.prof.release();
         d.bsph_diel.release(); d.bbox_diel.release();
         d.gq_d.release(); d.cq_d.release(); d.gq_rs.release(); d.cq_rs.release(); d.gq_u32.release(); d.cq_u32.release();
         d.xq_d.release(); d.xq_rs.release(); d.xq_u32.release();
         d.wf_perm.release(); d.wf_key.release(); d.wf_bins.release();
+        d.cand_ids.release(); d.cand_n.release(); d.slow_list.release();
         for (EventPair &e : d.ev_glass) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         d.acc.release(); d.acc_seg.release(); d.acc_draw.release(); d.tiles_rgba.release();
         d.tiles_accum.release(); d.tiles_seg.release(); d.tiles_draw.release(); d.queue.release();
@@ -1505,7 +1621,7 @@ int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]) {
     for (int lv = 16; b.stack_need >= PT_BVH_STACK && lv >= 0; lv -= 16) b = ptbvh::build(world, finite, margin, lv);
     std::vector<int> seen(world.size(), 0);
     int widest = 0, outside = 0, nested = 0;
-    struct Item { int32_t node; float lo[3], hi[3]; };
+    struct Item { int32_t node; double lo[3], hi[3]; };
     std::vector<Item> st;
     if (!b.nodes.empty()) {
         Item r;
@@ -1528,25 +1644,26 @@ int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]) {
             // (centre / half-extent boxes are rounded one by one: a child's may stick out of its parent's by a few ulps, which
             // the walk does not care about -- every box holds its own content, that is all it relies on)
             for (int k = 0; k < 3; k++) {
-                const float slo = nd.c[k][s] - nd.h[k][s], shi = nd.c[k][s] + nd.h[k][s];
-                const float tol = 8.0f * 1.1920929e-7f * std::max(std::fabs(slo), std::fabs(shi));
+                const double slo = bvh_slot_lo(nd, k, s), shi = bvh_slot_hi(nd, k, s);
+                // (centre / half-extent boxes are rounded one by one: a child's may stick out of its parent's by a few ulps, which
+                // the walk does not care about -- every box holds its own content, that is all it relies on)
+                const double tol = 8.0 * 1.1920929e-7 * std::max(std::fabs(slo), std::fabs(shi));
                 if (slo < it.lo[k] - tol || shi > it.hi[k] + tol) nested++;
             }
             if (intm & (1u << s)) {
                 Item c;
-                c.node = nd.node_base + rank;
-                for (int k = 0; k < 3; k++) { c.lo[k] = nd.c[k][s] - nd.h[k][s]; c.hi[k] = nd.c[k][s] + nd.h[k][s]; }
+                c.node = bvh_node_base(nd) + rank;
+                for (int k = 0; k < 3; k++) { c.lo[k] = bvh_slot_lo(nd, k, s); c.hi[k] = bvh_slot_hi(nd, k, s); }
                 if (c.node <= it.node || c.node >= (int32_t)b.nodes.size()) { nested++; continue; }
                 st.push_back(c);
             } else {
-                const int32_t slot = nd.obj_base + rank;
+                const int32_t slot = bvh_obj_base(nd) + rank;
                 if (slot < 0 || slot >= (int32_t)b.order.size()) { outside++; continue; }
                 const int32_t oi = b.order[(size_t)slot];
                 seen[(size_t)oi]++;
                 const ptbvh::Aabb bb = ptbvh::object_bounds(world[(size_t)oi]);
                 for (int a = 0; a < 3; a++)
-                    if ((double)nd.c[a][s] - (double)nd.h[a][s] > bb.lo[a] - margin * 0.999 ||
-                        (double)nd.c[a][s] + (double)nd.h[a][s] < bb.hi[a] + margin * 0.999) { outside++; break; }
+                    if (bvh_slot_lo(nd, a, s) > bb.lo[a] - margin * 0.999 || bvh_slot_hi(nd, a, s) < bb.hi[a] + margin * 0.999) { outside++; break; }
             }
         }
     }

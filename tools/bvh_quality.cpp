@@ -109,20 +109,20 @@ int main(int argc, char **argv) {
                 if (!((nd.meta >> (8 + s)) & 1u) && !((nd.meta >> (12 + s)) & 1u)) continue;
                 double a0 = tmin, a1 = tmax;
                 for (int k = 0; k < 3; k++) {
-                    const double tc = ((double)nd.c[k][s] - ro[k]) * iv[k], th = (double)nd.h[k][s] * std::fabs(iv[k]);
+                    const double tc = (0.5 * (bvh_slot_lo(nd, k, s) + bvh_slot_hi(nd, k, s)) - ro[k]) * iv[k], th = 0.5 * (bvh_slot_hi(nd, k, s) - bvh_slot_lo(nd, k, s)) * std::fabs(iv[k]);
                     a0 = std::max(a0, tc - th);
                     a1 = std::min(a1, tc + th);
                 }
                 if (a1 < a0) continue;
                 const int rank = (int)((nd.meta >> (2 * s)) & 3u);
                 if ((nd.meta >> (12 + s)) & 1u) {
-                    const DevObj &o = world[(size_t)b.order[(size_t)(nd.obj_base + rank)]];
+                    const DevObj &o = world[(size_t)b.order[(size_t)(bvh_obj_base(nd) + rank)]];
                     tests++;
                     double t;
                     if ((o.kind == KIND_SPHERE) ? hit_sphere(o, ro, rd, tmin, tmax, t) : hit_box(o, ro, rd, tmin, tmax, t)) tmax = t;
                 } else {
                     key[nk] = a0;
-                    kid[nk++] = nd.node_base + rank;
+                    kid[nk++] = bvh_node_base(nd) + rank;
                 }
             }
             for (int i = 1; i < nk; i++)  // nearest first

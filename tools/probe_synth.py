@@ -11,7 +11,7 @@ w, h, spp, d = 1920, 1080, 16, 8
 for n in ns:
     t = time.time(); sc = hip.FlatScene(synth.make_scene(n, 1)); tg = time.time() - t
     img = np.zeros((h, w, 4), np.uint8)
-    cfg = hip.RenderConfig(w, h, spp, d, 1)
+    cfg = hip.RenderConfig(w, h, spp, d, int(os.environ.get("PROBE_SEED", "1")))
     t = time.time(); st = hip.render(sc, cfg, img, ctx=ctx); t1 = time.time() - t
     t = time.time(); st = hip.render(sc, cfg, img, ctx=ctx); dt = time.time() - t
     mm = L.pt_debug_scan_mismatches(ctx.handle) if os.environ.get("PTCORE_SCAN", "").startswith("verify") else -1
