@@ -45,6 +45,17 @@ def seg_flops(n_sphere: int, n_box: int, n_plane: int) -> float:
     return 23.0 * n_sphere + 12.0 * n_box + 14.0 * n_plane + 150.0
 
 
+# BASELINE.json's configs: scene, width, height, spp, max depth.  The default line is config 4, the one the metric is quoted on;
+# the others are parity-test cases that --config turns into bench lines for the per-config roofline evidence (profiles/r03_c*).
+CONFIGS = {
+    "C1": ("example_simple", 256, 256, 16, 4),
+    "C2": ("test_scene", 800, 600, 256, 8),
+    "C3": ("metal_glass_room", 1920, 1080, 1024, 12),
+    "C4": ("gpu_showcase", 1920, 1080, 1024, 8),
+    "C5": ("test_comprehensive", 3840, 2160, 4096, 16),
+}
+
+
 def host_cpu_quota() -> int:
     """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
     n = len(os.sched_getaffinity(0))
@@ -63,6 +74,8 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="one of BASELINE.json's configs instead of the default line (config 4); sets scene, size, spp and depth")
     ap.add_argument("--scene", default="gpu_showcase")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -72,7 +85,13 @@ def main() -> int:
     ap.add_argument("--spp-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded CPU-baseline sample")
+    pre, _ = ap.parse_known_args()
+    if pre.config:  # the config's scene, size, spp and depth become the defaults: an explicit --spp (the short PMC passes) still wins
+        sc_, w_, h_, spp_, d_ = CONFIGS[pre.config]
+        ap.set_defaults(scene=sc_, width=w_, height=h_, spp=spp_, depth=d_)
     args = ap.parse_args()
+    config_id = next((k for k, v in CONFIGS.items() if (v[0], v[1], v[2], v[4]) == (args.scene, args.width, args.height, args.depth)), None)
+    config_full = config_id is not None and CONFIGS[config_id][3] == args.spp  # (the PMC passes run a config at a fraction of its spp)
 
     import torch  # first: libptcore must resolve libamdhip64.so.7 to the copy torch already loaded
     import torch.distributed as dist
@@ -143,13 +162,23 @@ def main() -> int:
                                       C.c_void_p(frame.data_ptr()), W * 4, None, C.c_void_p(stream.cuda_stream)))
         return frame
 
+    gather_ms = [0.0]  # rank 0, world > 1: device time of the tile gather + untile of the timed steps (torch events on the current stream)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if world > 1 else None
+    pending = []
+
     def step():
         st = capi.PtStats()
         capi.check(L.pt_render_tiles_device(ctx.handle, C.byref(flat.c), C.byref(cfg), C.byref(shard),
                                             C.c_void_p(tiles.data_ptr()), None, C.c_void_p(stream.cuda_stream),
                                             C.byref(st)))
         if backend == "nccl" or world == 1:
+            if ev is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
             distributed.assemble_frame(tiles, W, H, rank, world, untile, scratch)
+            if ev is not None:
+                b.record(stream)
+                pending.append((a, b))
         else:  # rehearsal: gather through host memory
             host = tiles.cpu()
             bufs = distributed.gather_tiles(host, rank, world)
@@ -170,10 +199,12 @@ def main() -> int:
     for _ in range(args.warmup):
         step()
     fence()
+    pending.clear()
     t0 = time.perf_counter()
     stats = [step() for _ in range(args.steps)]
     fence()
     elapsed = time.perf_counter() - t0
+    gather_ms[0] = sum(a.elapsed_time(b) for a, b in pending) / max(1, args.steps)
 
     red_dev = dev if backend == "nccl" else torch.device("cpu")
     tot = torch.tensor([float(sum(s.segments for s in stats)), float(sum(s.samples for s in stats)),
@@ -227,12 +258,11 @@ def main() -> int:
         traffic = None
         traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        default_cfg = (world == 1 and args.scene == "gpu_showcase" and (W, H, args.spp, args.depth) == (1920, 1080, 1024, 8)
-                       and args.spp_chunk == 0)
+        default_cfg = world == 1 and config_full and args.spp_chunk == 0
         if os.path.exists(tpath) and default_cfg:  # the PMC passes were taken on exactly this workload and launch shape
             try:
-                with open(tpath) as f:
-                    tk = json.load(f).get(kernel_name, {})
+                with open(tpath) as f:  # (config 4 under the bare kernel name, the others under name@Cn)
+                    tk = json.load(f).get(kernel_name if config_id == "C4" else kernel_name + "@" + config_id, {})
                 # PMC bytes per algorithmic byte of the profiled launches x this run's algorithmic bytes per launch
                 if tk.get("hbm_bytes_per_alg_byte"):
                     traffic = tk["hbm_bytes_per_alg_byte"] * alg_bytes
@@ -261,11 +291,17 @@ def main() -> int:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "scenes/%s.json %dx%d, %d spp, max depth %d, seed %d (BASELINE config 4)"
-                                   % (args.scene, W, H, args.spp, args.depth, args.seed),
+            "config": {"workload": "scenes/%s.json %dx%d, %d spp, max depth %d, seed %d (%s)"
+                                   % (args.scene, W, H, args.spp, args.depth, args.seed,
+                                      ("BASELINE config %s" % config_id[1] + ("" if config_full else " at %d of its %d spp" % (args.spp, CONFIGS[config_id][3])))
+                                      if config_id else "not a BASELINE config"),
                        "tiles": "32x32 interleaved over %d rank(s)" % world, "gather": ("rccl" if backend == "nccl" else backend + " (rehearsal)") if world > 1 else "none",
                        "spp_chunk": chunk, "job_buffer_budget_mib": int(os.environ["PTCORE_L_BUDGET_MB"])},
             "per_rank_render_ms_per_step": busy_ms,
+            "per_rank_render_ms_min": min(busy_ms), "per_rank_render_ms_max": max(busy_ms),
+            # N > 1: the tile gather (RCCL over xGMI, ~1 MB per peer at 1080p) + untile on rank 0, device time between two events on
+            # the stream they run on (it includes the wait for the slowest rank's tiles); and what is left of the step
+            "gather_untile_device_ms_per_step": gather_ms[0] if world > 1 else 0.0,
             "gather_untile_host_ms_per_step": elapsed / steps * 1e3 - max(busy_ms),
             "primary_msamples_per_s": samples / elapsed / 1e6,
             "segments_per_sample": segments / max(samples, 1.0),

@@ -1481,9 +1481,14 @@ __device__ __forceinline__ P pt_launder(P p) {
 // job; glass_kernel handles them together, and the paths that go on come back through the continuation queue.
 // The trace loop then never runs the dielectric branch, the exit search or its epilogue at 14 % of its lanes,
 // and no lane spends a whole trip through the scan on an exit search.
-// (launch bounds: the flat scans are asked to fit five waves per SIMD = 96 VGPRs, the BVH forms four = 128; the diagnostic form is not held to anything)
+// (launch bounds: the flat scans are asked to fit five waves per SIMD = 96 VGPRs, the BVH forms four = 128; so is the all-in-one form
+// of the grouped scan, which at 96 registers spilled 19 - 34 of them to scratch and only ever runs as the tail pass of a chunk, over
+// the few paths with more dielectric bounces than split rounds; the diagnostic form is not held to anything)
 template <bool STATS, bool PROF, int SCAN, bool SPLIT>
-__global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? PT_BVH_WAVES : PT_FLAT_WAVES) void trace_kernel(const TraceArgs A) {
+__global__ __launch_bounds__(PT_BLOCK, PROF ? 1
+                                       : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? PT_BVH_WAVES
+                                       : ((SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE) && !SPLIT && PT_FLAT_WAVES > 4) ? 4
+                                                                                                                               : PT_FLAT_WAVES) void trace_kernel(const TraceArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevFrame &F = A.F;
     const TraceBuffers &B = A.B;  // set-up and epilogue only; the loop reads the argument block through KA
@@ -1932,9 +1937,21 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1 : (SCAN == SCAN_BVH || SCAN == S
 // write their radiance record (always zero here: glass emits nothing).  One entry per lane, grid-stride.
 // VERIFY: the exit search is also done by the plain object-by-object loop and disagreements are counted.
 // WIDE: more than 32 spheres or boxes in the scene: the exit search takes its (dielectric-only) records in groups of 32.
+struct GlassArgs {  // the argument block of glass_kernel (one by-value kernel argument, i.e. the kernarg segment)
+    DevFrame F;
+    TraceBuffers B;
+};
 template <bool STATS, bool VERIFY, bool WIDE>
-__global__ __launch_bounds__(PT_BLOCK, PT_FLAT_WAVES) void glass_kernel(const DevFrame F, const TraceBuffers B) {
+__global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT_WAVES) void glass_kernel(const GlassArgs A) {  // (the grouped form spills 6 - 17 VGPRs at 96)
     extern __shared__ __align__(16) unsigned char smem[];
+    const DevFrame &F = A.F;
+    const TraceBuffers &B = A.B;  // set-up and epilogue only
+    // The loop reads two dozen queue pointers once per entry; kept in SGPRs for the whole loop they do not fit next to what the
+    // exit search holds, and the compiler parked 60 - 79 of them in VGPR lanes (v_readlane / v_writelane: 4-cycle VALU
+    // instructions).  As in trace_kernel they are re-read from the kernarg segment where they are used (KB).
+    typedef const GlassArgs __attribute__((address_space(4))) *ConstArgsPtr;
+    const ConstArgsPtr ka = (ConstArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+#define KB (&pt_launder(ka)->B)
     DevObj *lds_obj = reinterpret_cast<DevObj *>(smem);
     DevMat *lds_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
     int *lds_kidx = reinterpret_cast<int *>(smem + (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat));
@@ -1970,22 +1987,22 @@ __global__ __launch_bounds__(PT_BLOCK, PT_FLAT_WAVES) void glass_kernel(const De
 
     for (uint32_t i0 = blockIdx.x * PT_BLOCK + (threadIdx.x & ~(PT_WAVE - 1u)); i0 < n; i0 += gridDim.x * PT_BLOCK) {
         const uint32_t i = i0 + lane;
-        const bool live = i < n && B.glass.job[i] != PT_HOLE;
+        const bool live = i < n && KB->glass.job[i] != PT_HOLE;
         bool go_on = false;
         double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, Tx = 0, Ty = 0, Tz = 0;
         uint64_t rs = 0;
         uint32_t job = 0, j_seg = 0, j_draw = 0;
         int depth = 0;
         if (live) {
-            ox = B.glass.d[i]; oy = B.glass.d[qg + i]; oz = B.glass.d[2 * qg + i];
-            dx = B.glass.d[3 * qg + i]; dy = B.glass.d[4 * qg + i]; dz = B.glass.d[5 * qg + i];
-            Tx = B.glass.d[6 * qg + i]; Ty = B.glass.d[7 * qg + i]; Tz = B.glass.d[8 * qg + i];
-            const double tmax = B.glass.d[9 * qg + i];
-            rs = B.glass.rs[i];
-            job = B.glass.job[i];
-            depth = B.glass.depth[i];
-            const int best = B.glass.best[i];
-            if (STATS) { j_seg = B.glass.jseg[i]; j_draw = B.glass.jdraw[i]; }
+            ox = KB->glass.d[i]; oy = KB->glass.d[qg + i]; oz = KB->glass.d[2 * qg + i];
+            dx = KB->glass.d[3 * qg + i]; dy = KB->glass.d[4 * qg + i]; dz = KB->glass.d[5 * qg + i];
+            Tx = KB->glass.d[6 * qg + i]; Ty = KB->glass.d[7 * qg + i]; Tz = KB->glass.d[8 * qg + i];
+            const double tmax = KB->glass.d[9 * qg + i];
+            rs = KB->glass.rs[i];
+            job = KB->glass.job[i];
+            depth = KB->glass.depth[i];
+            const int best = KB->glass.best[i];
+            if (STATS) { j_seg = KB->glass.jseg[i]; j_draw = KB->glass.jdraw[i]; }
 
             // hit record of the winner
             const DevObj &o = lds_obj[best];
@@ -2035,7 +2052,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_FLAT_WAVES) void glass_kernel(const De
                             scan_uniform(F, g_obj, ray, 1, best2, tmax2);
                             if (ebest != best2 || (ebest >= 0 && !(etmax == tmax2))) {
                                 c_mismatch++;
-                                unsigned long long *dbg = B.counters + 8;
+                                unsigned long long *dbg = KB->counters + 8;
                                 dbg[0] = ((unsigned long long)(uint32_t)ebest << 32) | (uint32_t)best2;
                                 dbg[1] = ptm::to_bits(etmax);
                                 dbg[2] = ptm::to_bits(tmax2);
@@ -2052,10 +2069,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_FLAT_WAVES) void glass_kernel(const De
                 finished = roulette_advance<STATS>(depth, attx, atty, attz, Tx, Ty, Tz, rs, c_draw, j_draw);
             }
             if (finished) {
-                reinterpret_cast<double4 *>(B.L)[job] = make_double4(Tx * 0.0, Ty * 0.0, Tz * 0.0, 0.0);
+                reinterpret_cast<double4 *>(KB->L)[job] = make_double4(Tx * 0.0, Ty * 0.0, Tz * 0.0, 0.0);
                 if (STATS) {
-                    B.job_seg[job] = j_seg;
-                    B.job_draw[job] = j_draw;
+                    KB->job_seg[job] = j_seg;
+                    KB->job_draw[job] = j_draw;
                 }
             } else {
                 go_on = true;
@@ -2066,7 +2083,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_FLAT_WAVES) void glass_kernel(const De
             const uint32_t np = (uint32_t)__popcll(pm), room = q_end - q_cur;
             uint32_t nbase = 0;
             if (np > room) {
-                if (lane == 0) nbase = atomicAdd(B.cont.count, (uint32_t)PT_CONT_BLOCK);
+                if (lane == 0) nbase = atomicAdd(KB->cont.count, (uint32_t)PT_CONT_BLOCK);
                 nbase = __builtin_amdgcn_readfirstlane(nbase);
             }
             const uint32_t rank = lane_rank(pm);
@@ -2078,21 +2095,21 @@ __global__ __launch_bounds__(PT_BLOCK, PT_FLAT_WAVES) void glass_kernel(const De
                 q_cur += np;
             }
             if (go_on && slot >= B.cont.cap) {
-                atomicAdd(B.counters + 19, 1ull);  // cannot happen; never write outside the queue
+                atomicAdd(KB->counters + 19, 1ull);  // cannot happen; never write outside the queue
             } else if (go_on) {
-                B.cont.d[slot] = ox;
-                B.cont.d[qc + slot] = oy;
-                B.cont.d[2 * qc + slot] = oz;
-                B.cont.d[3 * qc + slot] = dx;
-                B.cont.d[4 * qc + slot] = dy;
-                B.cont.d[5 * qc + slot] = dz;
-                B.cont.d[6 * qc + slot] = Tx;
-                B.cont.d[7 * qc + slot] = Ty;
-                B.cont.d[8 * qc + slot] = Tz;
-                B.cont.rs[slot] = rs;
-                B.cont.job[slot] = job;
-                B.cont.depth[slot] = depth;
-                if (STATS) { B.cont.jseg[slot] = j_seg; B.cont.jdraw[slot] = j_draw; }
+                KB->cont.d[slot] = ox;
+                KB->cont.d[qc + slot] = oy;
+                KB->cont.d[2 * qc + slot] = oz;
+                KB->cont.d[3 * qc + slot] = dx;
+                KB->cont.d[4 * qc + slot] = dy;
+                KB->cont.d[5 * qc + slot] = dz;
+                KB->cont.d[6 * qc + slot] = Tx;
+                KB->cont.d[7 * qc + slot] = Ty;
+                KB->cont.d[8 * qc + slot] = Tz;
+                KB->cont.rs[slot] = rs;
+                KB->cont.job[slot] = job;
+                KB->cont.depth[slot] = depth;
+                if (STATS) { KB->cont.jseg[slot] = j_seg; KB->cont.jdraw[slot] = j_draw; }
                 c_cont++;
             }
         }
@@ -2104,6 +2121,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_FLAT_WAVES) void glass_kernel(const De
         if (w_draw) atomicAdd(&B.counters[2], (unsigned long long)w_draw);
         if (w_cont) atomicAdd(&B.counters[6], (unsigned long long)w_cont);
     }
+#undef KB
     if (VERIFY) {
         const uint32_t w_mis = wave_sum(c_mismatch);
         if (lane == 0 && w_mis) atomicAdd(&B.counters[4], (unsigned long long)w_mis);

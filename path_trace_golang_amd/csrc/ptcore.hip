@@ -506,7 +506,7 @@ TraceFn pick_trace(bool stats, bool prof, int scan, bool split = false) {
     }
 }
 
-using GlassFn = void (*)(const DevFrame, const TraceBuffers);
+using GlassFn = void (*)(const ptk::GlassArgs);
 GlassFn pick_glass(bool stats, int scan) {
     using namespace ptk;
     if (scan == SCAN_VERIFY) return stats ? glass_kernel<true, true, false> : glass_kernel<false, true, false>;
@@ -1072,7 +1072,12 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
                 if (!fr.has_glass) break;  // nothing can have entered the glass queue: the frame is done
                 EventPair &e = d.ev_glass[d.n_glass++];
                 HIP_TRY(hipEventRecord(e.a, d.stream));
-                hipLaunchKernelGGL(pick_glass(fr.stats_on, fr.scan), dim3(glass_grid), dim3(PT_BLOCK), fr.glass_lds_bytes, d.stream, F, B);
+                {
+                    ptk::GlassArgs GA;
+                    GA.F = F;
+                    GA.B = B;
+                    hipLaunchKernelGGL(pick_glass(fr.stats_on, fr.scan), dim3(glass_grid), dim3(PT_BLOCK), fr.glass_lds_bytes, d.stream, GA);
+                }
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(e.b, d.stream));
             }

@@ -9,7 +9,7 @@ TAG=${1:-r02}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-SHORT="--spp 192 --steps 1 --warmup 0 --no-cpu-baseline"   # two full chunks and a short one, the launch shapes of the full run
+SHORT="--spp ${SHORT_SPP:-192} --steps 1 --warmup 0 --no-cpu-baseline"   # the launch shapes of the full run at a fraction of its samples
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_under_trace.json 2> $OUT/trace.err || exit 1
 echo "trace pass done"
 i=0

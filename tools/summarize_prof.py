@@ -76,7 +76,13 @@ if isinstance(b, dict) and "roofline" in b:
     if k in derived and derived[k]["hbm_fetch_bytes_x2"]:
         alg = b["roofline"]["alg_bytes_per_launch"] * b["roofline"]["launches_per_step"] * b["steps"]
         hbm = derived[k]["hbm_fetch_bytes_x2"] + derived[k]["hbm_write_bytes"]
-        traffic[name] = {
+        m_cfg = re.search(r"BASELINE config (\d)", b["config"]["workload"])
+        key = name if (m_cfg and m_cfg.group(1) == "4") else name + "@C" + (m_cfg.group(1) if m_cfg else "x")
+        try:
+            traffic = json.load(open("profiles/pmc_traffic.json"))  # one file for every config: config 4 under the bare kernel name
+        except Exception:  # noqa: BLE001
+            traffic = {}
+        traffic[key] = {
             "hbm_bytes": hbm, "fetch_bytes_corrected_x2": derived[k]["hbm_fetch_bytes_x2"], "write_bytes": derived[k]["hbm_write_bytes"],
             "algorithmic_bytes": alg, "hbm_bytes_per_alg_byte": hbm / alg if alg else None,
             "workload": b["config"]["workload"],
