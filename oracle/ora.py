@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libptoracle.so")
+_LIB_PATH = os.environ.get("PTORACLE_LIB") or os.path.join(_HERE, "libptoracle.so")  # PTORACLE_LIB: a sanitizer build (oracle/Makefile)
 
 
 class OraMaterial(C.Structure):

@@ -2,6 +2,7 @@
 
     python -m path_trace_golang_amd.build            # everything
     python -m path_trace_golang_amd.build core       # libptcore.so only
+(ASan + UBSan builds of the host-side code and the CPU suite against them: tools/sanitize.py.)
 
 Artifacts are written in-tree (git-ignored, but shipped to the GPU box by gpurun):
     path_trace_golang_amd/libptcore.so   C ABI + gfx950 kernels        (csrc/ptcore.hip)

@@ -16,7 +16,7 @@ def host():
     from path_trace_golang_amd import build, capi
 
     build.build_all()
-    L = C.CDLL(os.path.join(ROOT, "path_trace_golang_amd", "libpthost.so"))
+    L = C.CDLL(os.environ.get("PTHOST_LIB") or os.path.join(ROOT, "path_trace_golang_amd", "libpthost.so"))  # PTHOST_LIB: a sanitizer build
     L.pth_last_error.restype = C.c_char_p
     L.pth_scene_load.restype = C.c_void_p
     L.pth_scene_load.argtypes = [C.c_char_p]
