@@ -61,7 +61,9 @@ void usage() {
                  "  -mode string\n    \trender mode: preview or final (default \"preview\")\n"
                  "  -out string\n    \toutput PNG file for headless render (default \"output.png\")\n"
                  "  -scene string\n    \tpath to scene JSON file (default \"scenes/example_simple.json\")\n"
-                 "  -scene-settings\n    \tlet the scene file's settings block override the mode preset (the editor's rule)\n"
+                 "  -scene-settings\n    \tlet the scene file's settings block override the mode preset (the editor's rule); with -mode final this also\n"
+                 "    \tapplies the editor's Final button (x4 samples, x2 depth, internal/ui/app.go:73-75), which in the editor is\n"
+                 "    \tindependent of the preset\n"
                  "  -seed uint\n    \tsample-stream seed (default 1, or PATHTRACER_SEED)\n"
                  "  -spp int\n    \tsamples per pixel (default: the mode preset)\n"
                  "  -width int\n    \timage width (default: the mode preset)\n");
