@@ -1,4 +1,4 @@
-"""Randomised scenes through every closest-hit strategy (candidate bitmasks, BVH, plain scan) vs the oracle.
+"""Randomised scenes through every closest-hit strategy (candidate bitmasks, BVH, plain scan) and every form of the loop vs the oracle.
 Objects overlap, touch, nest, share centres and sizes on a coarse grid on purpose: exact ties and rays that
 start inside several objects are the cases where a culled strategy could differ from the sequential loop."""
 import os
@@ -46,15 +46,23 @@ def contexts():
 
     out = {}
     old = os.environ.get("PTCORE_SCAN")
+    oldp = os.environ.get("PTCORE_PIPELINE")
     try:
         for mode in ("broad", "wide", "bvh", "uniform"):
             os.environ["PTCORE_SCAN"] = mode
             out[mode] = capi.Context(ndev=1)
+        # the two pass forms of the loop over the hierarchy: the FP64 traversal pass, and the FP32 walk + exact pass (ties,
+        # nested and coincident objects are where a bound that is not certain, or a core that is not inside, would show)
+        os.environ["PTCORE_SCAN"] = "bvh"
+        for pipe in ("wavefront", "walk32"):
+            os.environ["PTCORE_PIPELINE"] = pipe
+            out["bvh/" + pipe] = capi.Context(ndev=1)
     finally:
-        if old is None:
-            os.environ.pop("PTCORE_SCAN", None)
-        else:
-            os.environ["PTCORE_SCAN"] = old
+        for k, v in (("PTCORE_SCAN", old), ("PTCORE_PIPELINE", oldp)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     yield out
     for c in out.values():
         c.close()
