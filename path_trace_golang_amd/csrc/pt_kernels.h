@@ -1153,12 +1153,15 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_kernel(const DevFrame F, cons
 // that every global store is a full coalesced row: (A) lockstep: stream init, u, v, the point on the focus plane;
 // (B) the rejection walk; (C) lockstep: lens offset, ray, stores.  Same draws in the same order per job as
 // raygen_kernel (renderer.go:182-183, camera.go:60-74).
-#define PT_RG_ROWS 4
+#ifndef PT_RG_ROWS
+#define PT_RG_ROWS 2  // (4 in round 2; with the cheaper sample stream of round 3 the kernel is bound by its stores, and two rows = 26 KB of LDS = six
+                      // blocks per CU beat four rows' better balance: 26.0 against 28.2 ms per C4 frame, 3 rows 26.9; profiles/r03_raygen_rows_ab.txt)
+#endif
 __global__ __launch_bounds__(PT_BLOCK) void raygen_lens_kernel(const DevFrame F, const DevCamera cam, double *__restrict__ ray,
                                                                  unsigned long long *__restrict__ ray_rng,
                                                                  uint16_t *__restrict__ ray_ndraw) {
     // per job, plane by plane (lane-minor: conflict-free): the point on the focus plane, the accepted lens sample, the
-    // stream state and the draws so far (0xffffffff: pixel outside the frame, or no such job); 52 KB: three blocks per CU
+    // stream state and the draws so far (0xffffffff: pixel outside the frame, or no such job); 13 KB per row
     __shared__ double s_ax[PT_RG_ROWS][PT_BLOCK], s_ay[PT_RG_ROWS][PT_BLOCK], s_az[PT_RG_ROWS][PT_BLOCK];
     __shared__ double s_rx[PT_RG_ROWS][PT_BLOCK], s_ry[PT_RG_ROWS][PT_BLOCK];
     __shared__ unsigned long long s_rs[PT_RG_ROWS][PT_BLOCK];
