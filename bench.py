@@ -278,6 +278,8 @@ def main() -> int:
         # kernel rate of the path work: every trace pass plus glass_kernel
         rank0_seg_per_s = sum(s.segments for s in stats) / max((trace_ms + glass_ms) * 1e-3, 1e-12)
         fp64_tops = rank0_seg_per_s * fseg / 1e12
+        clocks = [s.shader_clock_mhz for s in stats if s.shader_clock_mhz > 0]
+        clock_mhz = sum(clocks) / len(clocks) if clocks else None
         out = {
             "metric": "Msamples/s (rays x bounces/s) at %dx%dx%dspp" % (W, H, args.spp),
             "value": segments / elapsed / 1e6,
@@ -317,6 +319,10 @@ def main() -> int:
             "roofline_fp64": {"bound": "fp64_valu", "achieved": fp64_tops, "peak": FP64_PEAK_NOFMA_TOPS,
                               "unit": "Tflop/s (unfused)", "frac": fp64_tops / FP64_PEAK_NOFMA_TOPS,
                               "frac_of_fma_peak": fp64_tops / (2.0 * FP64_PEAK_NOFMA_TOPS),
+                              # the clock the trace kernels actually held (pt_stats.shader_clock_mhz: shader cycles over the 100 MHz
+                              # reference counter, one wave per launch) and the fraction of the unfused peak AT that clock
+                              "shader_clock_mhz": clock_mhz,
+                              "frac_at_measured_clock": (fp64_tops / (256 * 4 * 16 * clock_mhz * 1e6 / 1e12)) if clock_mhz else None,
                               "alg_flops_per_segment": fseg,
                               "trace_share_of_step": (trace_ms + glass_ms) / max(elapsed * 1e3, 1e-9),
                               "trace_ms_per_step": trace_ms / steps, "glass_ms_per_step": glass_ms / steps,

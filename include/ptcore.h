@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 /* status codes; pt_last_error() holds the text (thread-local) */
 enum {
@@ -165,6 +165,10 @@ typedef struct pt_stats {
     uint64_t continuations;   /* paths glass_kernel handed back through the continuation queue */
     uint64_t split_cont_in;   /* continuation entries taken up by split trace passes (the rest finish in the all-in-one pass) */
     uint64_t split_finished;  /* paths that ended inside a split trace pass */
+    /* ABI 3: the shader clock the trace kernels actually ran at: one wave per launch reads the shader-cycle counter
+     * (s_memtime) and the 100 MHz reference counter (s_memrealtime) when it starts and when it retires; the ratio of
+     * the sums over the frame's trace launches (0 when no trace launch was observed) */
+    double shader_clock_mhz;
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

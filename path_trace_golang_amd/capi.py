@@ -17,7 +17,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PTCORE_LIB") or os.path.join(PKG, "libptcore.so")  # PTCORE_LIB: another build of the same ABI (A/B runs)
 
-PT_ABI_VERSION = 2
+PT_ABI_VERSION = 3
 PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_ERR_NOMEM, PT_ERR_STATE = range(6)
 PT_MAT_LAMBERT, PT_MAT_METAL, PT_MAT_DIELECTRIC, PT_MAT_EMISSIVE, PT_MAT_MIRROR = range(5)
 PT_OBJ_UNKNOWN, PT_OBJ_SPHERE, PT_OBJ_PLANE, PT_OBJ_BOX, PT_OBJ_SPHERE_LIGHT = -1, 0, 1, 2, 3
@@ -74,7 +74,7 @@ class PtStats(C.Structure):
                 ("per_device_ms", C.c_double * 8), ("raygen_ms", C.c_double), ("glass_ms", C.c_double),
                 ("trace_split_ms", C.c_double), ("glass_launches", C.c_int32), ("trace_split_launches", C.c_int32),
                 ("glass_events", C.c_uint64), ("continuations", C.c_uint64), ("split_cont_in", C.c_uint64),
-                ("split_finished", C.c_uint64)]
+                ("split_finished", C.c_uint64), ("shader_clock_mhz", C.c_double)]
 
     def as_dict(self) -> dict:
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "per_device_ms"}

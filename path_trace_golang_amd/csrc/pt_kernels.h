@@ -1550,6 +1550,12 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
     const BroadLists<ConstSphPtr, ConstBoxPtr> BL{g_bs, g_bb, F.n_bsph, F.n_bbox, F.sph_all, F.box_all, F.sph_diel, F.box_diel,
                                                   lds_kidx, lds_kidx + F.n_bsph};
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
+    // the shader clock this launch runs at (pt_stats.shader_clock_mhz): the first wave of the launch notes the shader-cycle and the
+    // 100 MHz reference counters now and again when it retires (in memory, not in registers: the loop has none to spare)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        B.counters[44] = __builtin_amdgcn_s_memtime();
+        B.counters[45] = __builtin_amdgcn_s_memrealtime();
+    }
     const BvhNode *const bvh_nodes_ = B.bvh_nodes;
     const BvhObj *const bvh_objs_ = B.bvh_objs;
 
@@ -1910,6 +1916,11 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
         }
     }
 
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&B.counters[46], t1 - __hip_atomic_load(&B.counters[44], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        atomicAdd(&B.counters[47], r1 - __hip_atomic_load(&B.counters[45], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
     // counters: one atomic per wave
     const uint32_t w_seg = wave_sum(c_seg), w_exit = wave_sum(c_exit), w_draw = wave_sum(c_draw),
                    w_samples = wave_sum(c_samples);

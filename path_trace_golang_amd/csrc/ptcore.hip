@@ -1176,6 +1176,7 @@ int32_t dev_collect(Device &d, pt_stats *st, int slot) {
     st->exit_scans += c[1];
     st->draws += c[2];
     st->samples += c[3];
+    if (c[47]) st->shader_clock_mhz = (double)c[46] / ((double)c[47] / 100.0);  // cycles / (ticks of the 100 MHz counter) = MHz (device 0 of the last collected)
     st->glass_events += c[5];
     st->continuations += c[6];
     st->split_cont_in += c[7];

@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.PtSky) == 8 + 12 * 8
     assert C.sizeof(capi.PtScene) == 13 * 8 + 104 + 8 + 16
     assert C.sizeof(capi.PtConfig) == 32
-    assert C.sizeof(capi.PtStats) == 4 * 8 + 4 * 8 + 4 * 4 + 8 * 8 + 8 + 2 * 8 + 2 * 4 + 4 * 8  # ABI 2: + glass_ms, trace_split_ms, two launch counts, four path-queue counters
+    assert C.sizeof(capi.PtStats) == 4 * 8 + 4 * 8 + 4 * 4 + 8 * 8 + 8 + 2 * 8 + 2 * 4 + 4 * 8 + 8  # ABI 2: + glass_ms, trace_split_ms, two launch counts, four path-queue counters; ABI 3: + shader_clock_mhz
 
 
 def test_no_device_is_an_error_not_a_fallback():
