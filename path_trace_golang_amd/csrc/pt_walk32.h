@@ -5,11 +5,13 @@
 //   wf_walk32_kernel   walks the hierarchy in FP32 ONLY.  It never decides a hit: for every path of the level it lists the
 //                      objects whose own (inflated, outward-rounded) FP32 box the ray pierces before `tmaxf` -- the
 //                      candidates -- and shrinks `tmaxf` only by bounds that are CERTAIN: a ray that passes through the
-//                      middle of an object (a box shrunk by twice the margin, the cube inscribed in a shrunk sphere) is
-//                      hit by the reference's FP64 test no later than where it enters that core.  No FP64 ray, reciprocals
-//                      or path state are alive during the walk, so the kernel needs half the registers of scan_bvh and
-//                      runs at twice the waves per SIMD; no lane ever waits for an exact test, so the visit loop runs on
-//                      (nearly) full waves.
+//                      middle of an object (its CORE: a box shrunk by the margin on every side, the cube inscribed in a
+//                      sphere shrunk by the margin; ptbvh::object_core) is hit by the reference's FP64 test no later than
+//                      where it enters that core.  The cores live in a twin of every node (ptbvh::build_cores), so a core
+//                      visit is the same instructions as a node visit.  No FP64 ray, reciprocals or path state are alive
+//                      during the walk, so the kernel needs half the registers of scan_bvh and runs at twice the waves per
+//                      SIMD; no lane ever waits for an exact test.  (Measured: slower than the FP64 loop all the same --
+//                      more visits, a heavier visit, and the passes around it)
 //   wf_shade32_kernel  the exact pass, one path per lane: the reference's FP64 tests (objects.go:37-61, :141-179) on the
 //                      listed candidates only, the planes, `wins` (the order-free statement of renderer.go:297-302), then
 //                      the shading of wf_shade_kernel.  wf_exit32_kernel likewise for the exit searches (renderer.go:329-349).
