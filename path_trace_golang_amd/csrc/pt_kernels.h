@@ -495,6 +495,19 @@ struct BroadLists {
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(bx.h[0], aivxf, tcx_), __builtin_fmaf(bx.h[1], aivyf, tcy_)),   \
                                      __builtin_fmaf(bx.h[2], aivzf, tcz_));
 
+// Candidate masks are built by shifting: mask = 2 * mask + keep, keep = !(a < b) -- one compare and ONE v_addc_co_u32 (the
+// compare's lane mask is the carry-in) where `mask |= keep ? bit : 0` cost a v_mov, a v_cndmask and a v_or per record (8 against 4
+// SIMD-cycles per record and wave, 26 records on C4).  NaN keeps the record (nlt), as before.  The k-th of n records ends up
+// in bit n - 1 - k; pt_record_slot() is the same map for the tables and masks that go with it.
+__device__ __forceinline__ void push_keep_bit(uint32_t &mask, float a, float b) {
+    asm("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(b) : "vcc");
+}
+// table / mask position of record i of n, taken in groups of 32: its group's base + the bit push_keep_bit leaves it in
+__host__ __device__ __forceinline__ int pt_record_slot(int i, int n) {
+    const int g = i & ~31, cnt = (n - g) < 32 ? (n - g) : 32;
+    return g + (cnt - 1 - (i - g));
+}
+
 // Broad phase in FP32 over inflated bounds + exact FP64 narrow phase over the survivors.
 // MODE: 0 closest hit, 1 exit search, -1 decided per lane by `mode_rt`.
 template <bool PROF, bool DBG, int MODE, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
@@ -543,8 +556,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     float tminf = (float)(tmin - ts);  // FP32 parameters are relative to the entry point
     tminf -= __builtin_fabsf(tminf) * 1e-2f + 1e-6f;  // a little below tMin - ts
     const float inv_a = __builtin_amdgcn_rcpf(fa);
-    // candidate masks: bit k of `cs` = k-th sphere record, bit k of `cb` = k-th box record (<= 32 of each;
-    // the bit is wave-uniform, so setting it costs one select and one or)
+    // candidate masks: the k-th of n sphere records in bit n - 1 - k of `cs`, likewise the boxes in `cb` (<= 32 of each; push_keep_bit)
     uint32_t cs = 0, cb = 0;
     for (int k = 0; k < BL.n_bsph; k++) {
         const auto &s = BL.bs[k];
@@ -556,8 +568,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         const float rem = s.rm2 - d2;  // >= 0: the line passes within the inflated radius
         const float w = __builtin_fmaxf(tminf - tca, 0.0f);  // > 0: closest approach lies before tMin
         // outside (rem < 0) or wholly behind (w^2 a > rem) in one compare, as w^2 a >= 0; NaN keeps the sphere
-        const bool miss = rem < w * w * fa;
-        cs = miss ? cs : (cs | (1u << k));
+        push_keep_bit(cs, rem, w * w * fa);
     }
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
     const float aivxf = __builtin_fabsf(ivxf), aivyf = __builtin_fabsf(ivyf), aivzf = __builtin_fabsf(ivzf);
@@ -567,8 +578,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     for (int k = 0; k < BL.n_bbox; k++) {
         const auto &bx = BL.bb[k];
         PT_BOX_SLABS(bx, t0, t1)
-        const bool miss = t1 < t0;
-        cb = miss ? cb : (cb | (1u << k));
+        push_keep_bit(cb, t1, t0);
     }
     if (!trust) { cs = BL.sph_all; cb = BL.box_all; }
     if (outside_all) { cs = 0; cb = 0; }
@@ -685,9 +695,8 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
             const float d2 = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, qz * qz));
             const float rem = s.rm2 - d2;
             const float w = __builtin_fmaxf(tminf - tca, 0.0f);
-            const bool miss = rem < w * w * fa;
-            cs = miss ? cs : (cs | (1u << k));
-            diel |= s.diel ? (1u << k) : 0u;  // wave-uniform: scalar unit
+            push_keep_bit(cs, rem, w * w * fa);
+            diel = (diel << 1) | (s.diel ? 1u : 0u);  // wave-uniform: scalar unit (same bit order as cs)
         }
         if (!trust) cs = cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
         if (outside_all) cs = 0;
@@ -720,9 +729,8 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
             for (int k = 0; k < cnt; k++) {
                 const auto &bx = BL.bb[base + k];
                 PT_BOX_SLABS(bx, t0, t1)
-                const bool miss = t1 < t0;
-                cb = miss ? cb : (cb | (1u << k));
-                diel |= bx.diel ? (1u << k) : 0u;
+                push_keep_bit(cb, t1, t0);
+                diel = (diel << 1) | (bx.diel ? 1u : 0u);
             }
             if (!trust) cb = cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
             if (outside_all) cb = 0;
@@ -1529,8 +1537,8 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
         const int n1 = F.nmat * (int)(sizeof(DevMat) / 8);
         for (int i = threadIdx.x; i < n1; i += PT_BLOCK) l1[i] = g1[i];
         if (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY || SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE) {
-            for (int i = threadIdx.x; i < F.n_bsph; i += PT_BLOCK) lds_kidx[i] = B.bsph[i].index;
-            for (int i = threadIdx.x; i < F.n_bbox; i += PT_BLOCK) lds_kidx[F.n_bsph + i] = B.bbox[i].index;
+            for (int i = threadIdx.x; i < F.n_bsph; i += PT_BLOCK) lds_kidx[pt_record_slot(i, F.n_bsph)] = B.bsph[i].index;
+            for (int i = threadIdx.x; i < F.n_bbox; i += PT_BLOCK) lds_kidx[F.n_bsph + pt_record_slot(i, F.n_bbox)] = B.bbox[i].index;
         }
         __syncthreads();
     }
@@ -1978,8 +1986,8 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
         uint64_t *l1 = reinterpret_cast<uint64_t *>(lds_mat);
         const int n1 = F.nmat * (int)(sizeof(DevMat) / 8);
         for (int i = threadIdx.x; i < n1; i += PT_BLOCK) l1[i] = g1[i];
-        for (int i = threadIdx.x; i < F.n_dsph; i += PT_BLOCK) lds_kidx[i] = B.bsph_diel[i].index;
-        for (int i = threadIdx.x; i < F.n_dbox; i += PT_BLOCK) lds_kidx[F.n_dsph + i] = B.bbox_diel[i].index;
+        for (int i = threadIdx.x; i < F.n_dsph; i += PT_BLOCK) lds_kidx[pt_record_slot(i, F.n_dsph)] = B.bsph_diel[i].index;
+        for (int i = threadIdx.x; i < F.n_dbox; i += PT_BLOCK) lds_kidx[F.n_dsph + pt_record_slot(i, F.n_dbox)] = B.bbox_diel[i].index;
         __syncthreads();
     }
     typedef const DevObj __attribute__((address_space(4))) *ConstObjPtr;

@@ -376,8 +376,8 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_scan_flat_kernel(const WfArgs A) 
         uint64_t *l0 = reinterpret_cast<uint64_t *>(lds_obj);
         const int n0 = F.nobj * (int)(sizeof(DevObj) / 8);
         for (int i = threadIdx.x; i < n0; i += PT_BLOCK) l0[i] = g0[i];
-        for (int i = threadIdx.x; i < F.n_bsph; i += PT_BLOCK) lds_kidx[i] = B.bsph[i].index;
-        for (int i = threadIdx.x; i < F.n_bbox; i += PT_BLOCK) lds_kidx[F.n_bsph + i] = B.bbox[i].index;
+        for (int i = threadIdx.x; i < F.n_bsph; i += PT_BLOCK) lds_kidx[pt_record_slot(i, F.n_bsph)] = B.bsph[i].index;
+        for (int i = threadIdx.x; i < F.n_bbox; i += PT_BLOCK) lds_kidx[F.n_bsph + pt_record_slot(i, F.n_bbox)] = B.bbox[i].index;
         __syncthreads();
     }
     typedef const DevObj __attribute__((address_space(4))) *ConstObjPtr;

@@ -407,7 +407,6 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
             if (!(s.rm2 == s.rm2)) s.rm2 = INFINITY;
             s.index = (int32_t)i;
             s.diel = (o.kind & 0x100) ? 1 : 0;
-            if (fr.bsph.size() < 32 && (o.kind & 0x100)) F.sph_diel |= 1u << fr.bsph.size();
             fr.bsph.push_back(s);
             if (o.kind & 0x100) fr.bsph_diel.push_back(s);
         } else if (kind == KIND_BOX) {
@@ -427,7 +426,6 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
             }
             b.index = (int32_t)i;
             b.diel = (o.kind & 0x100) ? 1 : 0;
-            if (fr.bbox.size() < 32 && (o.kind & 0x100)) F.box_diel |= 1u << fr.bbox.size();
             fr.bbox.push_back(b);
             if (o.kind & 0x100) fr.bbox_diel.push_back(b);
         } else {
@@ -436,6 +434,11 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
     }
     F.n_bsph = (int32_t)fr.bsph.size();
     F.n_bbox = (int32_t)fr.bbox.size();
+    // the dielectric records among the first 32 of each kind, in the bit order of the kernels' candidate masks (push_keep_bit)
+    for (int i = 0; i < F.n_bsph && i < 32 && F.n_bsph <= 32; i++)
+        if (fr.bsph[(size_t)i].diel) F.sph_diel |= 1u << ptk::pt_record_slot(i, F.n_bsph);
+    for (int i = 0; i < F.n_bbox && i < 32 && F.n_bbox <= 32; i++)
+        if (fr.bbox[(size_t)i].diel) F.box_diel |= 1u << ptk::pt_record_slot(i, F.n_bbox);
     F.n_plane = (int32_t)fr.plane_idx.size();
     F.planes_y = 1;
     for (int32_t i : fr.plane_idx) {
