@@ -61,6 +61,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the p
 #ifndef PT_FLAT_WAVES
 #define PT_FLAT_WAVES 5  // waves per SIMD the flat-scan trace kernels and glass_kernel are compiled for (A/B builds: -DPT_FLAT_WAVES=4|6)
 #endif
+#ifndef PT_SPLIT_WAVES
+#define PT_SPLIT_WAVES 6  // ... and the headline kernel (split form of the bitmask scan) for: since the candidate masks are built by
+                          // push_keep_bit it needs 87 registers; held to 80 it spills two and is 2.2 % faster at six waves than at five
+                          // (profiles/r03_occ_c4.txt, second block; before that change six waves lost 2.3 %)
+#endif
 #define PT_HOLE 0xffffffffu     // job id of a reserved but unused queue slot
 // The host sizes every path-state queue as (entries a pass can append) + (waves of the widest writer grid) x (the larger
 // window): queue_slack() in ptcore.hip.  What that arithmetic relies on:
@@ -1499,6 +1504,7 @@ template <bool STATS, bool PROF, int SCAN, bool SPLIT>
 __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                                        : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? PT_BVH_WAVES
                                        : ((SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE) && !SPLIT && PT_FLAT_WAVES > 4) ? 4
+                                       : (SCAN == SCAN_BROAD && SPLIT && !STATS)                                                  ? PT_SPLIT_WAVES
                                                                                                                                : PT_FLAT_WAVES) void trace_kernel(const TraceArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DevFrame &F = A.F;
