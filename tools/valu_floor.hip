@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -128,6 +129,26 @@ struct OpDesc { const char *name; int per_body; };
     X(PK_MUL_F32, "v_pk_mul_f32", 64, R8(EIGHT_D("v_pk_mul_f32", ", %16")))                                                   \
     X(PK_ADD_F32, "v_pk_add_f32", 64, R8(EIGHT_D("v_pk_add_f32", ", %16")))                                                   \
     X(RCP_F32, "v_rcp_f32", 64, R8(EIGHT_U("v_rcp_f32", "")))                                                                 \
+    X(PK_FMA_OPSEL, "v_pk_fma_f32, one source half splat by op_sel", 64, R8(EIGHT_D("v_pk_fma_f32", ", %16, %17 op_sel:[0,1,0] op_sel_hi:[1,1,1]"))) \
+    X(PK_ADD_S, "v_pk_add_f32 (sgpr pair source)", 64, R8(EIGHT_D("v_pk_add_f32", ", s[40:41]")))                             \
+    X(PK_FMA_S, "v_pk_fma_f32 (sgpr pair source)", 64, R8(EIGHT_D("v_pk_fma_f32", ", s[40:41], %17")))                        \
+    X(PK_FMA_DEP, "v_pk_fma_f32, ONE dependent chain per wave", 64,                                                            \
+      R8("v_pk_fma_f32 %0, %0, %16, %17\nv_pk_fma_f32 %0, %0, %16, %17\nv_pk_fma_f32 %0, %0, %16, %17\nv_pk_fma_f32 %0, %0, %16, %17\n" \
+         "v_pk_fma_f32 %0, %0, %16, %17\nv_pk_fma_f32 %0, %0, %16, %17\nv_pk_fma_f32 %0, %0, %16, %17\nv_pk_fma_f32 %0, %0, %16, %17\n")) \
+    X(PK_FMA_OPSEL_DEP, "v_pk_fma_f32 op_sel splat, ONE dependent chain per wave", 64,                                         \
+      R8("v_pk_fma_f32 %0, %0, %16, %17 op_sel:[0,1,0] op_sel_hi:[1,1,1]\nv_pk_fma_f32 %0, %0, %16, %17 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n" \
+         "v_pk_fma_f32 %0, %0, %16, %17 op_sel:[0,1,0] op_sel_hi:[1,1,1]\nv_pk_fma_f32 %0, %0, %16, %17 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n" \
+         "v_pk_fma_f32 %0, %0, %16, %17 op_sel:[0,1,0] op_sel_hi:[1,1,1]\nv_pk_fma_f32 %0, %0, %16, %17 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n" \
+         "v_pk_fma_f32 %0, %0, %16, %17 op_sel:[0,1,0] op_sel_hi:[1,1,1]\nv_pk_fma_f32 %0, %0, %16, %17 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n")) \
+    X(FMA_F32_DEP, "v_fma_f32, ONE dependent chain per wave", 64,                                                              \
+      R8("v_fma_f32 %8, %8, %18, %18\nv_fma_f32 %8, %8, %18, %18\nv_fma_f32 %8, %8, %18, %18\nv_fma_f32 %8, %8, %18, %18\n"     \
+         "v_fma_f32 %8, %8, %18, %18\nv_fma_f32 %8, %8, %18, %18\nv_fma_f32 %8, %8, %18, %18\nv_fma_f32 %8, %8, %18, %18\n"))   \
+    X(MUL_F32_DEP, "v_mul_f32, ONE dependent chain per wave", 64,                                                              \
+      R8("v_mul_f32 %8, %8, %18\nv_mul_f32 %8, %8, %18\nv_mul_f32 %8, %8, %18\nv_mul_f32 %8, %8, %18\n"                         \
+         "v_mul_f32 %8, %8, %18\nv_mul_f32 %8, %8, %18\nv_mul_f32 %8, %8, %18\nv_mul_f32 %8, %8, %18\n"))                       \
+    X(FMA_F64_DEP, "v_fma_f64, ONE dependent chain per wave", 64,                                                              \
+      R8("v_fma_f64 %0, %0, %16, %17\nv_fma_f64 %0, %0, %16, %17\nv_fma_f64 %0, %0, %16, %17\nv_fma_f64 %0, %0, %16, %17\n"     \
+         "v_fma_f64 %0, %0, %16, %17\nv_fma_f64 %0, %0, %16, %17\nv_fma_f64 %0, %0, %16, %17\nv_fma_f64 %0, %0, %16, %17\n"))   \
     X(READLANE, "v_readlane_b32", 64,                                                                                         \
       R8("v_readlane_b32 s40, %8, 1\nv_readlane_b32 s41, %9, 2\nv_readlane_b32 s42, %10, 3\nv_readlane_b32 s43, %11, 4\n"      \
          "v_readlane_b32 s44, %12, 5\nv_readlane_b32 s45, %13, 6\nv_readlane_b32 s46, %14, 7\nv_readlane_b32 s47, %15, 8\n"))  \
@@ -232,7 +253,8 @@ int main(int argc, char **argv) {
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int ncu = prop.multiProcessorCount;
     const auto fns = table(std::make_integer_sequence<int, OP_COUNT>{});
-    const int ks[] = {1, 2, 4, 5, 8};
+    const int ks[] = {1, 2, 4, 5, 6, 8};
+    const char *only = argc > 2 ? argv[2] : nullptr;  // run the ops whose name contains this
     Stamp *d;
     double *sink;
     unsigned int *arrive;
@@ -246,6 +268,7 @@ int main(int argc, char **argv) {
            "clock_mhz from s_memrealtime\", \"results\": [\n", prop.name, prop.gcnArchName, ncu, window);
     bool first = true;
     for (int op = 0; op < OP_COUNT; op++) {
+        if (only && !strstr(op_desc[op].name, only)) continue;
         for (int k : ks) {
             const int blocks = ncu * k;
             launch_fn f = fns[op];
