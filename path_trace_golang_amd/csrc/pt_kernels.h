@@ -1691,6 +1691,17 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 const uint32_t myjob = item - n_cont;
                 const auto kb = &KA->B;
                 const uint32_t nd = kb->ray_ndraw[myjob];
+                // the ray is fetched before nd is looked at (an out-of-frame job's slots exist too, their content is not used): one
+                // round trip to memory per refill instead of two in a row
+                // (assigned here, not under the test: the compiler would sink the loads back below it)
+                const size_t nj = F.njobs;
+                ox = kb->ray[myjob];
+                oy = kb->ray[nj + myjob];
+                oz = kb->ray[2 * nj + myjob];
+                dx = kb->ray[3 * nj + myjob];
+                dy = kb->ray[4 * nj + myjob];
+                dz = kb->ray[5 * nj + myjob];
+                rs = kb->ray_rng[myjob];
                 if (nd != 0xffffu && F.max_depth <= 0) {
                     // rayColorOpt returns black before any scan (renderer.go:287-289); the camera draws happened
                     c_samples++;
@@ -1710,14 +1721,6 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                     c_samples++;
                     c_draw += nd;
                     if (STATS) { j_seg = 0; j_draw = nd; }
-                    const size_t nj = F.njobs;
-                    ox = kb->ray[myjob];
-                    oy = kb->ray[nj + myjob];
-                    oz = kb->ray[2 * nj + myjob];
-                    dx = kb->ray[3 * nj + myjob];
-                    dy = kb->ray[4 * nj + myjob];
-                    dz = kb->ray[5 * nj + myjob];
-                    rs = kb->ray_rng[myjob];
                     SEC_END(SEC_RAYGEN)
                 }
             }
