@@ -2332,6 +2332,16 @@ __global__ __launch_bounds__(PT_BLOCK) void div_selftest_kernel(unsigned long lo
         const double q1 = div_shared(n, d, div_recip(d));
         const bool same = ptm::to_bits(q0) == ptm::to_bits(q1) || (q0 != q0 && q1 != q1);
         bad += same ? 0u : 1u;
+        // ptm::f_sqrt (the refinement without the range scaling) against the compiler's IEEE square root: the numerator as it is
+        // (either sign, any exponent every 16th time), its magnitude, and a magnitude pushed towards the scaling threshold 2^-767
+        {
+            const double x0 = n, x1 = ptm::f_abs(n), x2 = ptm::from_bits(((uint64_t)(200u + (uint32_t)((h2 >> 30) % 120u)) << 52) | mn);
+            const double r0 = ptm::f_sqrt(x0), r1 = ptm::f_sqrt(x1), r2 = ptm::f_sqrt(x2);
+            const double e0 = __builtin_sqrt(x0), e1 = __builtin_sqrt(x1), e2 = __builtin_sqrt(x2);
+            const bool same_sq = (ptm::to_bits(r0) == ptm::to_bits(e0) || (r0 != r0 && e0 != e0)) && ptm::to_bits(r1) == ptm::to_bits(e1) &&
+                                 ptm::to_bits(r2) == ptm::to_bits(e2);
+            bad += same_sq ? 0u : 1u;
+        }
         // math.Max / math.Min: the one-instruction forms against the spelled-out ones, on the same operands and on the
         // special values (zeros of both signs, infinities, NaN, 1, denormals) in every combination over the run
         const uint64_t sp[8] = {0x0ULL, 0x8000000000000000ULL, 0x7ff0000000000000ULL, 0xfff0000000000000ULL,
