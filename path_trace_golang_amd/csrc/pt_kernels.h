@@ -226,6 +226,7 @@ __device__ __forceinline__ bool sphere_exact(double cx, double cy, double cz, do
 }
 
 // The same with the two divisions by a = |d|^2 sharing ya = div_recip(a) (a within 2^+-340: the caller's `tame` test).
+template <bool OUTLINE_SQRT = true>
 __device__ __forceinline__ bool sphere_exact_shared(double cx, double cy, double cz, double radius_sq, const RayD &r, double a, double ya,
                                                     double tmin, double tmax, double &t) {
     const double ocx = r.ox - cx, ocy = r.oy - cy, ocz = r.oz - cz;
@@ -235,7 +236,7 @@ __device__ __forceinline__ bool sphere_exact_shared(double cx, double cy, double
     const double disc = halfB * halfB - a * c;
     bool valid = false;
     if (!(disc < 0)) {
-        const double sq = ptm::f_sqrt(disc);
+        const double sq = ptm::f_sqrt<OUTLINE_SQRT>(disc);
         double root = div_shared(-halfB - sq, a, ya);
         valid = true;
         if (root < tmin || root > tmax) {
@@ -1049,7 +1050,7 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                     valid = box_exact<true>(bo.o.a[0], bo.o.a[1], bo.o.a[2], bo.o.b[0], bo.o.b[1], bo.o.b[2], r, ivx, ivy, ivz, tmin,
                                       ptm::max_float64(), t);
                 else
-                    valid = sphere_exact_shared(bo.o.a[0], bo.o.a[1], bo.o.a[2], bo.o.radius_sq, r, a, ya, tmin, tmax, t);
+                    valid = sphere_exact_shared<false>(bo.o.a[0], bo.o.a[1], bo.o.a[2], bo.o.radius_sq, r, a, ya, tmin, tmax, t);
                 if (valid && wins(mode, is_box, i, t, best, best_is_box, tmax) &&
                     (mode == 0 || exit_candidate_ok(bo.o, kind, r, t))) {
                     best = i;

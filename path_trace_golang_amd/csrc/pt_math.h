@@ -46,6 +46,12 @@ PT_HD double max_float64() { return from_bits(0x7fefffffffffffffULL); }
 // fix-up for zeros and infinity (a class test and two selects).  For a positive normal x >= 2^-767 -- every root the kernels
 // take, bar the exact zeros -- the scaling is by 2^0 and the fix-up does nothing: the same refinement without them gives the same
 // bits (checked against __builtin_sqrt on 4 * 10^9 operands by pt_debug_div_selftest); everything else takes the builtin.
+#if defined(__HIP_DEVICE_COMPILE__)
+// (the compiler's sequence as a function of its own: inlined next to the short form it costs the trace kernel registers it does not
+// have -- the stream state went to scratch memory across the cosine sampling -- while hardly any root ever comes here)
+__device__ __attribute__((noinline)) inline double f_sqrt_any(double x) { return __builtin_sqrt(x); }
+#endif
+template <bool OUTLINE = true>  // false: the compiler's sequence inlined too (the BVH walk: a call inside its loop costs it more)
 PT_HD double f_sqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t e = (uint32_t)(to_bits(x) >> 52);  // sign and exponent field
@@ -60,8 +66,10 @@ PT_HD double f_sqrt(double x) {
         d = __builtin_fma(-g, g, x);
         return __builtin_fma(d, h, g);
     }
-#endif
+    return OUTLINE ? f_sqrt_any(x) : __builtin_sqrt(x);
+#else
     return __builtin_sqrt(x);
+#endif
 }
 
 // math.Min / math.Max with Go's special cases (-Inf/+Inf win, NaN propagates,
