@@ -1669,44 +1669,53 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
             const bool take = !active && rank < avail;
             const uint32_t nneed = (uint32_t)__popcll(need);
             const uint32_t item = cur + rank;
+            const uint32_t cur0 = cur;  // (wave-uniform: the claimed range's addresses are a scalar base + the lane's rank)
             cur += nneed < avail ? nneed : avail;
 
             if (CONT && take && item < n_cont) {
                 // a path that left glass_kernel: its whole state comes from the continuation queue
                 const auto cq = &KA->B.cont;
                 const size_t qc = cq->cap;
-                job = cq->job[item];
+                // (addresses as the scalar base of the wave's claim + rank, see the fresh rays below)
+                const uint32_t rk = rank & 63u;
+                const size_t c0 = cur0;
+                job = (cq->job + c0)[rk];
                 active = job != PT_HOLE;  // a slot some wave of glass_kernel reserved and did not fill
                 if (SPLIT && active) c_contin++;
                 mode = 0;
-                depth = cq->depth[item];
-                ox = cq->d[item];
-                oy = cq->d[qc + item];
-                oz = cq->d[2 * qc + item];
-                dx = cq->d[3 * qc + item];
-                dy = cq->d[4 * qc + item];
-                dz = cq->d[5 * qc + item];
-                Tx = cq->d[6 * qc + item];
-                Ty = cq->d[7 * qc + item];
-                Tz = cq->d[8 * qc + item];
-                rs = cq->rs[item];
+                depth = (cq->depth + c0)[rk];
+                const double *q0 = cq->d + c0;
+                ox = q0[rk];
+                oy = (q0 + qc)[rk];
+                oz = (q0 + 2 * qc)[rk];
+                dx = (q0 + 3 * qc)[rk];
+                dy = (q0 + 4 * qc)[rk];
+                dz = (q0 + 5 * qc)[rk];
+                Tx = (q0 + 6 * qc)[rk];
+                Ty = (q0 + 7 * qc)[rk];
+                Tz = (q0 + 8 * qc)[rk];
+                rs = (cq->rs + c0)[rk];
                 if (STATS) { j_seg = cq->jseg[item]; j_draw = cq->jdraw[item]; }
             } else if (take) {
                 // the primary ray of this job was generated by raygen_kernel (coherent pre-pass)
                 const uint32_t myjob = item - n_cont;
                 const auto kb = &KA->B;
-                const uint32_t nd = kb->ray_ndraw[myjob];
+                // addresses as (scalar base of the wave's claim) + rank: no 64-bit vector arithmetic per plane
+                const uint32_t rk = rank & 63u;  // (rank < 64: said so, the offset fits the 32-bit lane offset of a scalar-base load)
+                const int64_t jb = (int64_t)cur0 - (int64_t)n_cont;  // job of rank 0 (below zero while the claim still holds continuations)
+                const uint32_t nd = (kb->ray_ndraw + jb)[rk];
                 // the ray is fetched before nd is looked at (an out-of-frame job's slots exist too, their content is not used): one
                 // round trip to memory per refill instead of two in a row
                 // (assigned here, not under the test: the compiler would sink the loads back below it)
                 const size_t nj = F.njobs;
-                ox = kb->ray[myjob];
-                oy = kb->ray[nj + myjob];
-                oz = kb->ray[2 * nj + myjob];
-                dx = kb->ray[3 * nj + myjob];
-                dy = kb->ray[4 * nj + myjob];
-                dz = kb->ray[5 * nj + myjob];
-                rs = kb->ray_rng[myjob];
+                const double *r0 = kb->ray + jb;
+                ox = r0[rk];
+                oy = (r0 + nj)[rk];
+                oz = (r0 + 2 * nj)[rk];
+                dx = (r0 + 3 * nj)[rk];
+                dy = (r0 + 4 * nj)[rk];
+                dz = (r0 + 5 * nj)[rk];
+                rs = (kb->ray_rng + jb)[rk];
                 if (nd != 0xffffu && F.max_depth <= 0) {
                     // rayColorOpt returns black before any scan (renderer.go:287-289); the camera draws happened
                     c_samples++;
@@ -1906,6 +1915,7 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 }
                 const uint32_t rank = lane_rank(pm);
                 const uint32_t slot = rank < room ? g_cur + rank : nbase + (rank - room);
+                const uint32_t g_cur0 = g_cur;
                 if (np > room) {
                     g_cur = nbase + (np - room);
                     g_end = nbase + PT_QUEUE_BLOCK;
@@ -1917,21 +1927,29 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                     active = false;
                 } else if (to_glass) {
                     const size_t qc = gq->cap;
-                    gq->d[slot] = ox;
-                    gq->d[qc + slot] = oy;
-                    gq->d[2 * qc + slot] = oz;
-                    gq->d[3 * qc + slot] = dx;
-                    gq->d[4 * qc + slot] = dy;
-                    gq->d[5 * qc + slot] = dz;
-                    gq->d[6 * qc + slot] = Tx;
-                    gq->d[7 * qc + slot] = Ty;
-                    gq->d[8 * qc + slot] = Tz;
-                    gq->d[9 * qc + slot] = tmax;
-                    gq->rs[slot] = rs;
-                    gq->job[slot] = job;
-                    gq->depth[slot] = depth;
-                    gq->best[slot] = best;
-                    if (STATS) { gq->jseg[slot] = j_seg; gq->jdraw[slot] = j_draw; }
+                    // entry `idx` past slot `base` of every plane
+                    auto store_entry = [&](size_t base, uint32_t idx) {
+                        double *q0 = gq->d + base;
+                        q0[idx] = ox;
+                        (q0 + qc)[idx] = oy;
+                        (q0 + 2 * qc)[idx] = oz;
+                        (q0 + 3 * qc)[idx] = dx;
+                        (q0 + 4 * qc)[idx] = dy;
+                        (q0 + 5 * qc)[idx] = dz;
+                        (q0 + 6 * qc)[idx] = Tx;
+                        (q0 + 7 * qc)[idx] = Ty;
+                        (q0 + 8 * qc)[idx] = Tz;
+                        (q0 + 9 * qc)[idx] = tmax;
+                        (gq->rs + base)[idx] = rs;
+                        (gq->job + base)[idx] = job;
+                        (gq->depth + base)[idx] = depth;
+                        (gq->best + base)[idx] = best;
+                        if (STATS) { (gq->jseg + base)[idx] = j_seg; (gq->jdraw + base)[idx] = j_draw; }
+                    };
+                    // nearly every push fits the wave's window: the addresses are then a scalar base (the window cursor) + the lane's
+                    // rank, which costs no 64-bit vector arithmetic per plane (14 planes); a push that straddles two windows goes by slot
+                    if (np <= room) store_entry(g_cur0, rank & 63u);
+                    else store_entry(0, slot);
                     active = false;
                     c_glass++;
                 }
