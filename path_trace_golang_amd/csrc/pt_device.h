@@ -80,7 +80,7 @@ static_assert(sizeof(BroadBox) == 32, "BroadBox layout");
 // (Round 3 also built and measured a 48-byte node -- the slot boxes on an 8-bit grid of the node's own, three 16-byte loads
 // per visit instead of seven: profiles/r03_qnode_ab.txt.  The walks are bound by vector-instruction issue, not by the
 // loads: the 35 instructions that decode such a node cost more than its four saved loads give back.)
-struct alignas(128) BvhNode {   // one 128-byte cache line per node (108 bytes used)
+struct alignas(128) BvhNode {   // one 128-byte cache line per node (108 bytes used; scan_bvh reads the first 96 only: ptcore.hip embeds the three words below in the low bytes of h)
     float c[3][4];    // [axis][slot] centre of the slot's inflated box
     float h[3][4];    // half extent, rounded up so that [c - h, c + h] holds it (the slab test is then three fma per axis and slot
                       // pair, no min / max to order the planes: see PT_BOX_SLABS in pt_kernels.h)

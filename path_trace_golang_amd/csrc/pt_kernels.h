@@ -978,7 +978,13 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 hb = 0xfu;
                 t0[0] = t0[1] = t0[2] = t0[3] = 0.0f;
             }
-            const uint32_t meta = nd.meta;
+            // node_base, obj_base and meta from the low bytes of the half extents (ptcore.hip puts them there): the record's last 32
+            // bytes are never requested
+#define PT_LOWBYTES(a, n4) \
+    (__builtin_amdgcn_perm(__float_as_uint(nd.h[a][1]), __float_as_uint(nd.h[a][0]), 0x0c0c0400u) | \
+     ((n4) ? __builtin_amdgcn_perm(__float_as_uint(nd.h[a][3]), __float_as_uint(nd.h[a][2]), 0x04000c0cu) \
+           : __builtin_amdgcn_perm(0u, __float_as_uint(nd.h[a][2]), 0x0c000c0cu)))
+            const uint32_t meta = PT_LOWBYTES(2, false);
             const uint32_t oh = hb & (meta >> 12) & 0xfu;  // object children pierced
             // internal children nearest first: sort keys = entry parameter (>= 0, so its bits order like the
             // value) with 2*slot in the low three bits; 0xffffffff = not a candidate
@@ -1001,7 +1007,7 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                 k1 = m0 < m1 ? m0 : m1;
                 k2 = m0 < m1 ? m1 : m0;
             }
-            const int nbase = nd.node_base;
+            const int nbase = (int)PT_LOWBYTES(0, true);
 #define PT_CHILD(k) (nbase + (int)((meta >> ((k) & 7u)) & 3u))
             if (k1 != 0xffffffffu) {  // sorted: k2 and k3 can only be candidates when k1 is
                 if (k2 != 0xffffffffu) {
@@ -1024,8 +1030,9 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
             if (oh != 0) {
                 pend = oh;
                 pend_meta = meta;
-                pend_base = nd.obj_base;
+                pend_base = (int)PT_LOWBYTES(1, true);
             }
+#undef PT_LOWBYTES
             PH_END(SEC_COSINE)
             }
         }

@@ -1326,6 +1326,23 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
             nd.obj_base += obj_off;
             sd.bvh_nodes.push_back(nd);
         }
+        // The walk of scan_bvh reads the first 96 bytes of a node only (six 16-byte requests per lane and visit instead of seven: the
+        // CU's address unit, not the caches, is what its visits wait for -- DESIGN 10.3): node_base, obj_base and meta ride in the LOW BYTES
+        // of the twelve half extents, which are rounded up to a multiple of 256 ulp first (they only ever had to be upper bounds).
+        // The fields themselves stay where they were for everything else that reads a node (host tools, the walk32 form).
+        for (BvhNode &nd : sd.bvh_nodes) {
+            const uint32_t payload[3] = {(uint32_t)nd.node_base, (uint32_t)nd.obj_base, nd.meta & 0xffffffu};
+            for (int k = 0; k < 3; k++)
+                for (int sl = 0; sl < 4; sl++) {
+                    uint32_t b;
+                    std::memcpy(&b, &nd.h[k][sl], 4);
+                    if ((b & 0x7f800000u) == 0x7f800000u || (b >> 31)) b = 0x7f7fff00u;  // inf (unbounded slab) / NaN: the largest finite float
+                    else b = (b + 0xffu) & ~0xffu;                                          // up to the next multiple of 256 ulp
+                    if (b >= 0x7f800000u) b = 0x7f7fff00u;
+                    b |= (payload[k] >> (8 * sl)) & 0xffu;
+                    std::memcpy(&nd.h[k][sl], &b, 4);
+                }
+        }
         sd.bvh_objs.resize(built.order.size() + builtd.order.size());
         for (size_t k = 0; k < sd.bvh_objs.size(); k++) {
             const int32_t oi = k < built.order.size() ? built.order[k] : builtd.order[k - built.order.size()];
