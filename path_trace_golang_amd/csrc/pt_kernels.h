@@ -507,6 +507,18 @@ __device__ __forceinline__ float pt_vmax(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+__device__ __forceinline__ float pt_vmin(float a, float b) {
+    float d;
+    asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// One v_pk_fma_f32 over two slots with the ray constant taken from ONE half of a register pair (op_sel picks the half for both
+// results; SELC_LO / SELC_HI pick the halves of the addend: 0,1 = the pair as it is).
+#define PT_PK_FMA(dst, a, b, c, SEL_B, SELC_LO, SELC_HI, NEG_A)                                                                \
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0," #SEL_B "," #SELC_LO "] op_sel_hi:[1," #SEL_B "," #SELC_HI "] neg_lo:[" #NEG_A \
+        ",0,0] neg_hi:[" #NEG_A ",0,0]"                                                                                        \
+        : "=v"(dst)                                                                                                            \
+        : "v"(a), "v"(b), "v"(c))
 __device__ __forceinline__ float pt_vmax3(float a, float b, float c) {
     float d;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -896,11 +908,10 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     // component, which unconstrains the slab)
     const float inflf = CAREFUL ? (float)clip.infl * 1.0001f : 0.0f;
     const float exf = inflf * __builtin_fabsf(ivxf), eyf = inflf * __builtin_fabsf(ivyf), ezf = inflf * __builtin_fabsf(ivzf);
-    const v2f ivx2 = {ivxf, ivxf}, ivy2 = {ivyf, ivyf}, ivz2 = {ivzf, ivzf};
-    const v2f nox2 = {noxf, noxf}, noy2 = {noyf, noyf}, noz2 = {nozf, nozf};
-    const v2f aivx2 = {__builtin_fabsf(ivxf), __builtin_fabsf(ivxf)}, aivy2 = {__builtin_fabsf(ivyf), __builtin_fabsf(ivyf)},
-              aivz2 = {__builtin_fabsf(ivzf), __builtin_fabsf(ivzf)};
-    const v2f ex2 = {exf, exf}, ey2 = {eyf, eyf}, ez2 = {ezf, ezf};
+    // the per-ray constants two to a register pair, the half picked per instruction by op_sel (PT_PK_FMA): 5 pairs (6 with the
+    // widening) where the compiler's own splat handling gives each constant a pair of its own (9 / 12 pairs)
+    const v2f iv_xy = {ivxf, ivyf}, ivz_aivx = {ivzf, __builtin_fabsf(ivxf)}, aiv_yz = {__builtin_fabsf(ivyf), __builtin_fabsf(ivzf)};
+    const v2f no_xy = {noxf, noyf}, noz_ex = {nozf, exf}, ey_ez = {eyf, ezf};
     float tmaxf = (float)(tmax - ts);
     tmaxf += __builtin_fabsf(tmaxf) * 4.8e-7f;  // >= tmax - ts (MaxFloat64 becomes +inf)
     int sp = resume ? S.sp : 0;
@@ -951,26 +962,33 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
                           cz = {nd.c[2][2 * p], nd.c[2][2 * p + 1]};
                 const v2f hx = {nd.h[0][2 * p], nd.h[0][2 * p + 1]}, hy = {nd.h[1][2 * p], nd.h[1][2 * p + 1]},
                           hz = {nd.h[2][2 * p], nd.h[2][2 * p + 1]};
-                const v2f tcx = __builtin_elementwise_fma(cx, ivx2, nox2), tcy = __builtin_elementwise_fma(cy, ivy2, noy2),
-                          tcz = __builtin_elementwise_fma(cz, ivz2, noz2);
+                v2f tcx, tcy, tcz;
+                PT_PK_FMA(tcx, cx, iv_xy, no_xy, 0, 0, 0, 0);
+                PT_PK_FMA(tcy, cy, iv_xy, no_xy, 1, 1, 1, 0);
+                PT_PK_FMA(tcz, cz, ivz_aivx, noz_ex, 0, 0, 0, 0);
                 v2f nx_, ny_, nz_, fx_, fy_, fz_;
                 if (CAREFUL) {  // every bound widened by the lane's own inflation (in parameter units: exf, eyf, ezf)
-                    const v2f thx = __builtin_elementwise_fma(hx, aivx2, ex2), thy = __builtin_elementwise_fma(hy, aivy2, ey2),
-                              thz = __builtin_elementwise_fma(hz, aivz2, ez2);
+                    v2f thx, thy, thz;
+                    PT_PK_FMA(thx, hx, ivz_aivx, noz_ex, 1, 1, 1, 0);
+                    PT_PK_FMA(thy, hy, aiv_yz, ey_ez, 0, 0, 0, 0);
+                    PT_PK_FMA(thz, hz, aiv_yz, ey_ez, 1, 1, 1, 0);
                     nx_ = tcx - thx; ny_ = tcy - thy; nz_ = tcz - thz;
                     fx_ = tcx + thx; fy_ = tcy + thy; fz_ = tcz + thz;
                 } else {
-                    nx_ = __builtin_elementwise_fma(-hx, aivx2, tcx); ny_ = __builtin_elementwise_fma(-hy, aivy2, tcy);
-                    nz_ = __builtin_elementwise_fma(-hz, aivz2, tcz);
-                    fx_ = __builtin_elementwise_fma(hx, aivx2, tcx); fy_ = __builtin_elementwise_fma(hy, aivy2, tcy);
-                    fz_ = __builtin_elementwise_fma(hz, aivz2, tcz);
+                    PT_PK_FMA(nx_, hx, ivz_aivx, tcx, 1, 0, 1, 1);
+                    PT_PK_FMA(ny_, hy, aiv_yz, tcy, 0, 0, 1, 1);
+                    PT_PK_FMA(nz_, hz, aiv_yz, tcz, 1, 0, 1, 1);
+                    PT_PK_FMA(fx_, hx, ivz_aivx, tcx, 1, 0, 1, 0);
+                    PT_PK_FMA(fy_, hy, aiv_yz, tcy, 0, 0, 1, 0);
+                    PT_PK_FMA(fz_, hz, aiv_yz, tcz, 1, 0, 1, 0);
                 }
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const int s = 2 * p + q;
                     // v_min/v_max return the other operand for a NaN: a NaN slab (0 * inf) constrains nothing
-                    t0[s] = __builtin_fmaxf(__builtin_fmaxf(nx_[q], ny_[q]), __builtin_fmaxf(nz_[q], tminf));
-                    const float t1 = __builtin_fminf(__builtin_fminf(fx_[q], fy_[q]), __builtin_fminf(fz_[q], tmaxf));
+                    // (as instructions: the builtins would first quiet every operand that comes out of an asm statement)
+                    t0[s] = pt_vmax3(nx_[q], ny_[q], pt_vmax(nz_[q], tminf));
+                    const float t1 = pt_vmin3(fx_[q], fy_[q], pt_vmin(fz_[q], tmaxf));
                     hb |= (t1 < t0[s]) ? 0u : (1u << s);
                 }
             }

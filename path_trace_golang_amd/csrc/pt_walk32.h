@@ -54,11 +54,7 @@ struct Walk32Args {
 // One v_pk_fma_f32 over two node slots with the ray constant taken from ONE half of a register pair (op_sel picks the
 // half for both results): nine per-ray constants live in five pairs instead of nine (the compiler's own splat handling
 // gives every constant a pair of its own, 18 registers in scan_bvh).
-#define PT_PK_FMA(dst, a, b, c, SEL_B, SELC_LO, SELC_HI, NEG_A)                                                                \
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0," #SEL_B "," #SELC_LO "] op_sel_hi:[1," #SEL_B "," #SELC_HI "] neg_lo:[" #NEG_A \
-        ",0,0] neg_hi:[" #NEG_A ",0,0]"                                                                                        \
-        : "=v"(dst)                                                                                                            \
-        : "v"(a), "v"(b), "v"(c))
+// (PT_PK_FMA: pt_kernels.h)
 // v_max3 / v_min3 on the packed results (as instructions: through the builtins the compiler first quiets every operand
 // that comes out of an asm statement, one v_max_f32 x, x each).  Like v_max / v_min they return the other operand for a
 // NaN: a NaN slab parameter (0 * inf) constrains nothing.
