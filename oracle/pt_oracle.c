@@ -206,7 +206,7 @@ static uint64_t mix64(uint64_t z) {
 }
 
 /* key = one splitmix64 finaliser over (seed key + (pixel << 32 | sample)); the MWC64X state is (x, c) = (low word,
- * (high word >> 1) + 1): 0 < c < 2^31 < MWC_A keeps it off the generator's two fixed points. */
+ * (high word >> 1) + 1): 1 <= c <= 2^31 < MWC_A keeps it off the generator's two fixed points. */
 uint64_t ora_stream_init(uint64_t seed, uint64_t pixel, uint64_t sample) {
     uint64_t h = mix64(mix64(seed + GOLDEN) + ((pixel << 32) | (sample & 0xffffffffULL)));
     uint32_t x = (uint32_t)h, c = ((uint32_t)(h >> 32) >> 1) + 1u;

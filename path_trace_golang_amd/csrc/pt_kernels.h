@@ -1849,6 +1849,14 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                     best = fh.best;
                     tmax = fh.tmax;
                     scanned = true;
+                    if (SCAN == SCAN_VERIFY_BVH) {  // the verify instantiation checks this path like the walks above
+                        int best2;
+                        double tmax2;
+                        scan_uniform(F, g_obj, RayD{ox, oy, oz, dx, dy, dz}, mode, best2, tmax2);
+                        if (best != best2 || (best >= 0 && !(tmax == tmax2))) c_mismatch++;
+                        best = best2;
+                        tmax = tmax2;
+                    }
                 }
                 if (lane == 0) atomicAdd(KA->B.counters + 23, 1ull);
             }

@@ -207,7 +207,10 @@ PT_HD double go_pow5(double x) {
 //   key    h = mix64(mix64(seed + G) + (pixel << 32 | sample))      pixel < 2^28, sample < 2^31: one 64-bit word, one
 //              splitmix64 finaliser (a bijection: distinct (pixel, sample) give distinct h)
 //   state  MWC64X (D. B. Thomas, "The MWC64X Random Number Generator", 2011): x = low word of h, carry
-//              c = (high word >> 1) + 1, so that 0 < c < 2^31 < A: never one of the two fixed points (0, 0), (2^32-1, A-1)
+//              c = (high word >> 1) + 1, so that 1 <= c <= 2^31 < A: never one of the two fixed points (0, 0), (2^32-1, A-1).
+//              The shift drops bit 32 of h: the state is a 63-bit function of the 64-bit key, so two (pixel, sample) whose
+//              hashes differ in that bit alone share a stream -- about N^2 / 2^64 such pairs among N streams (~60 in the
+//              3.4 * 10^10 of a C5 frame): distinct streams are overwhelmingly likely, not guaranteed.
 //   step   out = x ^ c;  (c, x) <- A * x + c   with A = 4294883355; A * 2^32 - 1 is a safe prime, every other state
 //              lies on one of two cycles of A * 2^31 - 1 ~ 2^63 steps.  One v_mad_u64_u32 and one v_xor_b32 on gfx950.
 //   draw   two steps: (out1 << 21 | out2 >> 11) * 2^-53.

@@ -345,6 +345,14 @@ __global__ __launch_bounds__(PT_BLOCK, PT_BVH_WAVES) void wf_traverse_kernel(con
                     best = fh.best;
                     tmax = fh.tmax;
                     scanned = true;
+                    if (VERIFY) {  // the verify instantiation checks this path like the walks above
+                        int best2;
+                        double tmax2;
+                        scan_uniform(F, g_obj, RayD{ox, oy, oz, dx, dy, dz}, MODE, best2, tmax2);
+                        if (best != best2 || (best >= 0 && !(tmax == tmax2))) c_mismatch++;
+                        best = best2;
+                        tmax = tmax2;
+                    }
                 }
                 if (lane == 0) atomicAdd(B.counters + 23, 1ull);
             }

@@ -121,6 +121,7 @@ struct Device {
     std::vector<char> trace_is_split;  // per trace launch of the frame: the split form?
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     bool first_recorded = false;
+    unsigned long long pass_log_prev[24] = {};  // PTCORE_DEBUG_PASS_LOG: the counters after the previous pass of this frame
     // frame state
     pt_shard shard{0, 1};
     int32_t nlocal = 0;
@@ -577,6 +578,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
     d.acc_started = false;
     d.n_trace = d.n_resolve = d.n_raygen = d.n_glass = 0;
     d.first_recorded = false;
+    std::memset(d.pass_log_prev, 0, sizeof d.pass_log_prev);  // the device counters are cleared below, once per frame
     if (d.scene_gen != sd.gen) {
         HIP_TRY(d.objs.reserve(std::max<size_t>(1, world.size())));
         HIP_TRY(d.mats.reserve(mats.size()));
@@ -1051,11 +1053,11 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
                 HIP_TRY(hipMemcpy(c, d.counters.p, sizeof c, hipMemcpyDeviceToHost));
                 float ms = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
-                static unsigned long long prev[24] = {};
+                unsigned long long *prev = d.pass_log_prev;
                 std::fprintf(stderr, "ptcore pass: %s grid %u  %.3f ms  segments +%llu  exit scans +%llu  parked +%llu  ended here +%llu  continuations in +%llu  -> %.1f Mseg/s\n",
                              split ? "trace<split>" : "trace<all-in-one>", grid, ms, c[0] - prev[0], c[1] - prev[1], c[5] - prev[5], c[18] - prev[18],
                              c[7] - prev[7], (double)(c[0] - prev[0]) / (ms * 1e3));
-                std::memcpy(prev, c, sizeof prev);
+                std::memcpy(prev, c, sizeof c);
             }
             return PT_OK;
         };
@@ -1273,9 +1275,12 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     // tests return NaN parameters, which its range tests accept (NaN compares false, objects.go:56-60, :110) and which then
     // poison `closest` for every later object of the loop.  Only the loop itself reproduces that: such a world takes the
     // plain object-by-object scan, whatever was asked for.
+    // The same for coordinates or sizes of 1e37 and more: every culled strategy keeps FP32 bounds of the objects, which must stay
+    // finite UPPER bounds (the hierarchy rounds its half extents up to a multiple of 256 ulp and has no room to do so within a
+    // factor 34 of FLT_MAX).
     for (const DevObj &o : sd.world) {
-        bool fin = std::isfinite(o.radius);
-        for (int k = 0; k < 3; k++) fin = fin && std::isfinite(o.a[k]) && std::isfinite(o.b[k]);
+        bool fin = std::fabs(o.radius) < 1e37;
+        for (int k = 0; k < 3; k++) fin = fin && std::fabs(o.a[k]) < 1e37 && std::fabs(o.b[k]) < 1e37;
         if (!fin) scan = ptk::SCAN_UNIFORM;
     }
     sd.scan = scan;
@@ -1313,10 +1318,14 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
             return fail(PT_ERR_INVALID, "BVH deeper than the traversal stack");
         // core twins (the FP32 walk of pt_walk32.h): inside-the-object boxes of the main tree's object slots; the dielectric
         // tree's twins are empty (an exit search takes no FP32 bound)
-        sd.bvh_cores = ptbvh::build_cores(built, w, margin);
-        sd.bvh_cores.resize(built.nodes.size() + builtd.nodes.size());
-        for (size_t q = built.nodes.size(); q < sd.bvh_cores.size(); q++) {
-            std::memset(&sd.bvh_cores[q], 0, sizeof(BvhNode));
+        // Only PTCORE_PIPELINE=walk32 reads them (and the bits 20-23 build_cores sets in the nodes' meta): the default loop neither
+        // builds nor uploads 128 B per node for nothing.
+        if (ctx->pipeline == 2) {
+            sd.bvh_cores = ptbvh::build_cores(built, w, margin);
+            sd.bvh_cores.resize(built.nodes.size() + builtd.nodes.size());
+            for (size_t q = built.nodes.size(); q < sd.bvh_cores.size(); q++) {
+                std::memset(&sd.bvh_cores[q], 0, sizeof(BvhNode));
+            }
         }
         const int32_t node_off = (int32_t)built.nodes.size(), obj_off = (int32_t)built.order.size();
         F.bvh_main_nodes = node_off;

@@ -3,6 +3,8 @@ components (which must follow the reference's sequential NaN behaviour through t
 import numpy as np
 import pytest
 
+from conftest import render_vs_oracle
+
 pytestmark = pytest.mark.gpu
 
 CAM = {"position": {"x": 0, "y": 1, "z": 6}, "target": {"x": 0, "y": 1, "z": 0}, "up": {"x": 0, "y": 1, "z": 0}, "fov": 50,
@@ -20,23 +22,11 @@ def V(x, y, z):
 
 
 def _check(gpu_ctx, oracle, doc, w=48, h=32, spp=3, depth=6, seed=3):
-    from path_trace_golang_amd import capi, hip, scene
+    from path_trace_golang_amd import scene
 
     sc = scene.Scene.decode(doc)
     o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=seed)
-    img = np.zeros((h, w, 4), np.uint8)
-    acc = np.zeros((h, w, 3))
-    nseg = np.zeros((h, w), np.uint32)
-    ndraw = np.zeros((h, w), np.uint32)
-    st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg, ndraw,
-                    ctx=gpu_ctx)
-    assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"]
-    assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
-    assert np.array_equal(img, o["rgba"])
-    ref = o["accum"]
-    both_nan = np.isnan(acc) & np.isnan(ref)
-    ok = both_nan | (np.abs(acc - ref) <= 4 * depth * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
-    assert np.all(ok)
+    render_vs_oracle(gpu_ctx, sc, o, w, h, spp, depth, seed)  # the counting build and the one that ships
     return o
 
 
@@ -153,15 +143,4 @@ def test_non_finite_geometry_follows_the_reference_loop(gpu_ctx, oracle):
             setattr(sc.objects[k].position, axis, val)
             doc["objects"][k]["position"][axis] = val
             o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=seed)
-            img = np.zeros((h, w, 4), np.uint8)
-            acc = np.zeros((h, w, 3))
-            nseg = np.zeros((h, w), np.uint32)
-            ndraw = np.zeros((h, w), np.uint32)
-            st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg, ndraw,
-                            ctx=gpu_ctx)
-            assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"], (typ, axis, k)
-            assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
-            assert np.array_equal(img, o["rgba"])
-            ref = o["accum"]
-            both_nan = np.isnan(acc) & np.isnan(ref)
-            assert np.all(both_nan | (np.abs(acc - ref) <= 4 * depth * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300)))
+            render_vs_oracle(gpu_ctx, sc, o, w, h, spp, depth, seed, tag=(typ, axis, k))  # <*,*,SCAN_UNIFORM,false>, both builds

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import render_vs_oracle
+
 pytestmark = pytest.mark.gpu
 
 MAT_KINDS = ["lambert", "metal", "dielectric", "emissive", "mirror"]
@@ -75,19 +77,8 @@ def _one_random_scene(contexts, oracle, rng, nobj, w, h, spp, depth, seed):
     o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=seed)
     sc = scene.Scene.decode(doc)
     for mode, ctx in contexts.items():
-        img = np.zeros((h, w, 4), np.uint8)
-        acc = np.zeros((h, w, 3))
-        nseg = np.zeros((h, w), np.uint32)
-        ndraw = np.zeros((h, w), np.uint32)
-        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc,
-                        nseg, ndraw, ctx=ctx)
-        assert st["segments"] == o["stats"]["segments"], (mode, seed)
-        assert st["draws"] == o["stats"]["draws"] and st["exit_scans"] == o["stats"]["exit_scans"], (mode, seed)
-        assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]), (mode, seed)
-        assert np.array_equal(img, o["rgba"]), (mode, seed)
-        ref = o["accum"]
-        ok = (np.isnan(acc) & np.isnan(ref)) | (np.abs(acc - ref) <= 4 * depth * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
-        assert np.all(ok), (mode, seed)
+        # the counting build and the one that ships, of every strategy
+        render_vs_oracle(ctx, sc, o, w, h, spp, depth, seed, tag=(mode, seed))
     return o["stats"]["segments"]
 
 
@@ -135,19 +126,8 @@ def test_random_render_configurations_match_oracle(gpu_ctx, oracle):
         seed = int(rng.integers(1, 1 << 40))
         sc = scene.load(scene_path(name))
         o = oracle.render(oracle.Scene.load(scene_path(name)), w, h, spp, depth, seed=seed)
-        img = np.zeros((h, w, 4), np.uint8)
-        acc = np.zeros((h, w, 3))
-        nseg = np.zeros((h, w), np.uint32)
-        ndraw = np.zeros((h, w), np.uint32)
-        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, chunk, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg,
-                        ndraw, ctx=gpu_ctx)
         tag = "case %d: %s %dx%d spp %d depth %d chunk %d seed %d" % (case, name, w, h, spp, depth, chunk, seed)
-        assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"], tag
-        assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]), tag
-        assert np.array_equal(img, o["rgba"]), tag
-        ref = o["accum"]
-        ok = (np.isnan(acc) & np.isnan(ref)) | (np.abs(acc - ref) <= 4 * max(depth, 1) * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
-        assert np.all(ok), tag
+        render_vs_oracle(gpu_ctx, sc, o, w, h, spp, depth, seed, chunk=chunk, tag=tag)
 
 
 def test_random_large_scenes_match_oracle(gpu_ctx, oracle):
@@ -165,16 +145,5 @@ def test_random_large_scenes_match_oracle(gpu_ctx, oracle):
         seed = int(rng.integers(1, 1 << 40))
         sc = synth.make_scene(n, int(rng.integers(1, 1000)))
         o = oracle.render(oracle.Scene(sc.encode()), w, h, spp, depth, seed=seed)
-        img = np.zeros((h, w, 4), np.uint8)
-        acc = np.zeros((h, w, 3))
-        nseg = np.zeros((h, w), np.uint32)
-        ndraw = np.zeros((h, w), np.uint32)
-        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, chunk, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg,
-                        ndraw, ctx=gpu_ctx)
         tag = "case %d: %d objects %dx%d spp %d depth %d chunk %d seed %d" % (case, n, w, h, spp, depth, chunk, seed)
-        assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"], tag
-        assert st["exit_scans"] == o["stats"]["exit_scans"], tag
-        assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]), tag
-        assert np.array_equal(img, o["rgba"]), tag
-        rel = np.abs(acc - o["accum"]) / np.maximum(np.abs(o["accum"]), 1e-300)
-        assert rel.max() <= 4 * depth * 2.0 ** -52, tag
+        render_vs_oracle(gpu_ctx, sc, o, w, h, spp, depth, seed, chunk=chunk, tag=tag)

@@ -9,7 +9,7 @@ carries T=((a1*a2)*...)), bounded by depth * 2^-52 relative per sample.
 import numpy as np
 import pytest
 
-from conftest import SCENE_NAMES, scene_path
+from conftest import SCENE_NAMES, render_vs_oracle, scene_path
 
 pytestmark = pytest.mark.gpu
 
@@ -47,15 +47,17 @@ def _compare(ora_out, img, acc, nseg, ndraw, st, depth):
 def test_scene_small_matches_oracle(gpu_ctx, oracle, name):
     w, h, spp, depth = 96, 54, 8, 8
     o = oracle.render(oracle.Scene.load(scene_path(name)), w, h, spp, depth, seed=1)
-    img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, name, w, h, spp, depth, seed=1)
-    _compare(o, img, acc, nseg, ndraw, st, depth)
+    for stats in (True, False):  # the counting build and the one that ships
+        img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, name, w, h, spp, depth, seed=1, stats=stats)
+        _compare(o, img, acc, nseg, ndraw, st, depth)
 
 
 def test_c1_plumbing_config(gpu_ctx, oracle):
     # BASELINE config 1: example_simple 256x256, 16 spp, depth 4
+    from path_trace_golang_amd import scene
+
     o = oracle.render(oracle.Scene.load(scene_path("example_simple")), 256, 256, 16, 4, seed=1)
-    img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, "example_simple", 256, 256, 16, 4, seed=1)
-    _compare(o, img, acc, nseg, ndraw, st, 4)
+    render_vs_oracle(gpu_ctx, scene.load(scene_path("example_simple")), o, 256, 256, 16, 4, 1)
 
 
 def test_chunking_does_not_change_pixels(gpu_ctx):
@@ -73,20 +75,23 @@ def test_golden_fixture(gpu_ctx, name):
 
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     w, h, spp, depth, seed = (int(x) for x in g["cfg"])
-    img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, name, w, h, spp, depth, seed=seed)
-    assert [st["samples"], st["segments"], st["exit_scans"], st["draws"]] == [int(x) for x in g["totals"]]
-    assert np.array_equal(img, g["rgba"])
-    assert np.array_equal(nseg, g["nseg"]) and np.array_equal(ndraw, g["ndraw"])
-    rel = np.abs(acc - g["accum"]) / np.maximum(np.abs(g["accum"]), 1e-300)
-    assert rel.max() <= 4 * depth * 2.0 ** -52
+    for stats in (True, False):  # the counting build and the one that ships
+        img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, name, w, h, spp, depth, seed=seed, stats=stats)
+        assert [st["samples"], st["segments"], st["exit_scans"], st["draws"]] == [int(x) for x in g["totals"]]
+        assert np.array_equal(img, g["rgba"])
+        if stats:
+            assert np.array_equal(nseg, g["nseg"]) and np.array_equal(ndraw, g["ndraw"])
+        rel = np.abs(acc - g["accum"]) / np.maximum(np.abs(g["accum"]), 1e-300)
+        assert rel.max() <= 4 * depth * 2.0 ** -52
 
 
 @pytest.mark.parametrize("w,h", [(33, 31), (1, 1), (7, 100), (65, 9), (400, 225)])
 def test_ragged_frame_sizes(gpu_ctx, oracle, w, h):
     spp, depth = (2, 5) if w * h > 10000 else (5, 6)
     o = oracle.render(oracle.Scene.load(scene_path("test_scene")), w, h, spp, depth, seed=2)
-    img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, "test_scene", w, h, spp, depth, seed=2)
-    _compare(o, img, acc, nseg, ndraw, st, depth)
+    for stats in (True, False):
+        img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, "test_scene", w, h, spp, depth, seed=2, stats=stats)
+        _compare(o, img, acc, nseg, ndraw, st, depth)
 
 
 def test_deep_paths_reference_final_depth(gpu_ctx, oracle):
@@ -96,16 +101,20 @@ def test_deep_paths_reference_final_depth(gpu_ctx, oracle):
     img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, "metal_glass_room", w, h, spp, depth, seed=4)
     _compare(o, img, acc, nseg, ndraw, st, depth)
     assert int(nseg.max()) > 3 * 40  # some pixel really went deep
+    img2, acc2, _, _, st2 = _render_gpu(gpu_ctx, "metal_glass_room", w, h, spp, depth, seed=4, stats=False)
+    _compare(o, img2, acc2, None, None, st2, depth)  # the build that ships
+    assert np.array_equal(acc, acc2)
 
 
 def test_depth_zero_and_one(gpu_ctx, oracle):
     for depth in (0, 1, 2, 3):
         o = oracle.render(oracle.Scene.load(scene_path("example_simple")), 40, 30, 4, depth, seed=6)
-        img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, "example_simple", 40, 30, 4, depth, seed=6)
-        if depth == 0:
-            # rayColorOpt returns black before any scan (renderer.go:287-289); the camera draws are still made
-            assert not acc.any() and not o["accum"].any() and st["segments"] == 0 and st["draws"] > 0
-        _compare(o, img, acc, nseg, ndraw, st, depth)
+        for stats in (True, False):
+            img, acc, nseg, ndraw, st = _render_gpu(gpu_ctx, "example_simple", 40, 30, 4, depth, seed=6, stats=stats)
+            if depth == 0:
+                # rayColorOpt returns black before any scan (renderer.go:287-289); the camera draws are still made
+                assert not acc.any() and not o["accum"].any() and st["segments"] == 0 and st["draws"] > 0
+            _compare(o, img, acc, nseg, ndraw, st, depth)
 
 
 def test_seed_changes_image_and_is_reproducible(gpu_ctx):
@@ -220,6 +229,10 @@ def test_two_virtual_devices_in_process(oracle):
                             ndraw, ctx=ctx)
             assert st["num_devices"] == len(devs)
             _compare(o, img, acc, nseg, ndraw, st, depth)
+            img2 = np.zeros((h, w, 4), np.uint8)
+            acc2 = np.zeros((h, w, 3))
+            st2 = hip.render(sc, hip.RenderConfig(w, h, spp, depth, 5), img2, None, acc2, ctx=ctx)  # the build that ships
+            _compare(o, img2, acc2, None, None, st2, depth)
     # more devices than tiles: a 40x20 frame is two tiles, the third and fourth device own nothing
     w, h = 40, 20
     o = oracle.render(oracle.Scene.load(scene_path("test_comprehensive")), w, h, spp, depth, seed=5)
@@ -336,12 +349,15 @@ def test_full_size_windows_match_oracle(gpu_ctx, oracle, name, w, h, spp, depth,
         assert np.array_equal(img[sl], o["rgba"][sl])
         rel = np.abs(acc[sl] - o["accum"][sl]) / np.maximum(np.abs(o["accum"][sl]), 1e-300)
         assert rel.max() <= 4 * depth * 2.0 ** -52
-    if name == "gpu_showcase":
-        # the default chunking (91 spp per pass here) against one forced to 64: same pixels
+    # The same frame from the kernels that SHIP (no PT_FLAG_PIXEL_STATS: other instantiations -- the six-wave split kernel, 80
+    # registers -- than the counting ones above; what bench.py times): every byte, every sum and the totals must equal the
+    # frame the oracle windows just pinned.  For C4 with the chunk forced to 64 spp as well (default: 79 per pass).
+    for chunk in ((0, 64) if name == "gpu_showcase" else (0,)):
         img2 = np.zeros((h, w, 4), np.uint8)
         acc2 = np.zeros((h, w, 3))
-        hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 64), img2, None, acc2, ctx=gpu_ctx)
+        st2 = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, chunk), img2, None, acc2, ctx=gpu_ctx)
         assert np.array_equal(acc, acc2) and np.array_equal(img, img2)
+        assert [st2[k] for k in ("samples", "segments", "exit_scans", "draws")] == [st[k] for k in ("samples", "segments", "exit_scans", "draws")]
 
 
 def test_job_buffers_shrink_when_the_device_is_short_of_memory():
@@ -390,3 +406,8 @@ def test_many_samples_on_ragged_frames(gpu_ctx, oracle, w, h, spp):
     assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"]
     assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
     assert np.array_equal(img, o["rgba"])
+    img2 = np.zeros((h, w, 4), np.uint8)
+    acc2 = np.zeros((h, w, 3))
+    st2 = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed), img2, None, acc2, ctx=gpu_ctx)  # the build that ships
+    assert st2["spp_chunk"] >= 1024 and st2["segments"] == o["stats"]["segments"] and st2["draws"] == o["stats"]["draws"]
+    assert np.array_equal(img2, o["rgba"]) and np.array_equal(acc2, acc)

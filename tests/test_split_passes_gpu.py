@@ -19,7 +19,7 @@ MATS = [{"id": "d", "type": "lambert", "albedo": {"r": 0.7, "g": 0.6, "b": 0.5}}
         {"id": "e", "type": "emissive", "emit": {"r": 1, "g": 0.9, "b": 0.8}, "power": 6}]
 
 
-def _render(monkeypatch, rounds, sc, w, h, spp, depth, seed):
+def _render(monkeypatch, rounds, sc, w, h, spp, depth, seed, stats=True):
     from path_trace_golang_amd import capi, hip
 
     if rounds is None:
@@ -29,15 +29,17 @@ def _render(monkeypatch, rounds, sc, w, h, spp, depth, seed):
     with capi.Context(ndev=1) as ctx:  # read by pt_create
         img = np.zeros((h, w, 4), np.uint8)
         acc = np.zeros((h, w, 3))
-        nseg = np.zeros((h, w), np.uint32)
-        ndraw = np.zeros((h, w), np.uint32)
-        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS), img, None, acc, nseg, ndraw, ctx=ctx)
+        nseg = np.zeros((h, w), np.uint32) if stats else None
+        ndraw = np.zeros((h, w), np.uint32) if stats else None
+        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, seed, 0, capi.PT_FLAG_PIXEL_STATS if stats else 0), img, None, acc, nseg,
+                        ndraw, ctx=ctx)
     return st, img, acc, nseg, ndraw
 
 
 def _same_as_oracle(o, st, img, acc, nseg, ndraw, depth):
     assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"] and st["exit_scans"] == o["stats"]["exit_scans"]
-    assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
+    if nseg is not None:
+        assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
     assert np.array_equal(img, o["rgba"])
     ref = o["accum"]
     assert np.all(np.abs(acc - ref) <= 4 * depth * 2.0 ** -52 * np.maximum(np.abs(ref), 1e-300))
@@ -51,6 +53,9 @@ def test_any_number_of_split_rounds_gives_the_oracle_frame(monkeypatch, oracle, 
     o = oracle.render(oracle.Scene.load(scene_path(name)), w, h, spp, depth, seed=8)
     st, img, acc, nseg, ndraw = _render(monkeypatch, rounds, scene.load(scene_path(name)), w, h, spp, depth, 8)
     _same_as_oracle(o, st, img, acc, nseg, ndraw, depth)
+    st2, img2, acc2, _, _ = _render(monkeypatch, rounds, scene.load(scene_path(name)), w, h, spp, depth, 8, stats=False)
+    _same_as_oracle(o, st2, img2, acc2, None, None, depth)  # the build that ships
+    assert np.array_equal(acc, acc2)
     if rounds == 0:
         assert st["glass_events"] == 0 and st["glass_launches"] == 0
     else:
@@ -73,9 +78,10 @@ def test_paths_that_creep_through_a_glass_box_use_every_round(monkeypatch, oracl
     o = oracle.render(oracle.Scene(doc), w, h, spp, depth, seed=3)
     assert o["stats"]["exit_scans"] > 2 * w * h * spp  # glass nearly everywhere, several bounces deep
     for rounds in (None, 4):
-        st, img, acc, nseg, ndraw = _render(monkeypatch, rounds, scene.Scene.decode(doc), w, h, spp, depth, 3)
-        _same_as_oracle(o, st, img, acc, nseg, ndraw, depth)
-        assert st["glass_events"] > w * h * spp
+        for stats in (True, False):
+            st, img, acc, nseg, ndraw = _render(monkeypatch, rounds, scene.Scene.decode(doc), w, h, spp, depth, 3, stats=stats)
+            _same_as_oracle(o, st, img, acc, nseg, ndraw, depth)
+            assert st["glass_events"] > w * h * spp
 
 
 def test_full_size_frame_is_the_same_with_and_without_split_rounds(monkeypatch, gpu_ctx):
@@ -87,7 +93,7 @@ def test_full_size_frame_is_the_same_with_and_without_split_rounds(monkeypatch, 
     w, h, spp, depth = 1920, 1080, 6, 12
     frames = {}
     for rounds in (0, 2):
-        st, img, acc, _, _ = _render(monkeypatch, rounds, sc, w, h, spp, depth, 1)
+        st, img, acc, _, _ = _render(monkeypatch, rounds, sc, w, h, spp, depth, 1, stats=False)  # the builds that ship
         frames[rounds] = (st, img, acc)
     a, b = frames[0], frames[2]
     assert a[0]["segments"] == b[0]["segments"] and a[0]["draws"] == b[0]["draws"] and a[0]["exit_scans"] == b[0]["exit_scans"]
