@@ -237,7 +237,7 @@ def main() -> int:
             # (primary ray written by raygen_kernel: 6 doubles + 8 B stream state + 2 B draw count), 88 B per path taken
             # up from the continuation queue (9 doubles + stream state + job + depth), 24 B of radiance per path that
             # ends in it, 100 B per path it parks in the glass queue (10 doubles + stream state + job, depth, object)
-            kernel_name = "ptk::trace_kernel<false,false,1,true>"
+            kernel_name = "ptk::trace_kernel<false,false,1,1>"  # <STATS, PROF, SCAN_BROAD, FORM_SPLIT>
             n_launch = split_launches
             k_ms = sum(s.trace_split_ms for s in stats)
             alg_total = (58.0 * n_samples + 88.0 * sum(s.split_cont_in for s in stats) + 24.0 * sum(s.split_finished for s in stats)
@@ -246,7 +246,7 @@ def main() -> int:
                         "24 B radiance out per path ending, 100 B out per path parked for glass_kernel; the binding resource is VALU "
                         "issue, see roofline_fp64")
         else:
-            kernel_name = "ptk::trace_kernel<false,false,1,false>"
+            kernel_name = "ptk::trace_kernel<false,false,1,0>"
             n_launch = sum(s.trace_launches for s in stats)
             k_ms = trace_ms
             alg_total = (58.0 + 24.0) * n_samples

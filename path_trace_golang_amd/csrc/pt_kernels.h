@@ -1547,12 +1547,22 @@ __device__ __forceinline__ P pt_launder(P p) {
 // (launch bounds: the flat scans are asked to fit five waves per SIMD = 96 VGPRs, the BVH forms four = 128; so is the all-in-one form
 // of the grouped scan, which at 96 registers spilled 19 - 34 of them to scratch and only ever runs as the tail pass of a chunk, over
 // the few paths with more dielectric bounces than split rounds; the diagnostic form is not held to anything)
-template <bool STATS, bool PROF, int SCAN, bool SPLIT>
+// FORM: 0 = all-in-one, a dielectric exit search is the lane's next trip through the scan (every strategy);
+//       1 = split (above); 2 = all-in-one with the exit search NESTED: right after the shading of a dielectric front face, over the
+//       dielectric objects' own records only -- the form of the pass behind the split rounds, where nearly every lane's hit is glass
+//       (paths that creep through glass boxes): half of that pass's lane-trips were exit searches that each paid a whole
+//       trip through the broad phase over EVERY record (bitmask scans only).
+enum { FORM_ALL_IN_ONE = 0, FORM_SPLIT = 1, FORM_NESTED = 2 };
+template <bool STATS, bool PROF, int SCAN, int FORM>
 __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                                        : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? PT_BVH_WAVES
-                                       : ((SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE) && !SPLIT && PT_FLAT_WAVES > 4) ? 4
-                                       : (SCAN == SCAN_BROAD && SPLIT && !STATS)                                                  ? PT_SPLIT_WAVES
+                                       : ((SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE) && FORM != FORM_SPLIT && PT_FLAT_WAVES > 4) ? 4
+                                       : (SCAN == SCAN_BROAD && FORM == FORM_SPLIT && !STATS)                                                  ? PT_SPLIT_WAVES
                                                                                                                                : PT_FLAT_WAVES) void trace_kernel(const TraceArgs A) {
+    constexpr bool SPLIT = FORM == FORM_SPLIT;
+    constexpr bool NEST = FORM == FORM_NESTED;
+    static_assert(!NEST || SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY || SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE,
+                  "the nested exit search exists for the bitmask scans");
     extern __shared__ __align__(16) unsigned char smem[];
     const DevFrame &F = A.F;
     const TraceBuffers &B = A.B;  // set-up and epilogue only; the loop reads the argument block through KA
@@ -1592,6 +1602,11 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
         if (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY || SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE) {
             for (int i = threadIdx.x; i < F.n_bsph; i += PT_BLOCK) lds_kidx[pt_record_slot(i, F.n_bsph)] = B.bsph[i].index;
             for (int i = threadIdx.x; i < F.n_bbox; i += PT_BLOCK) lds_kidx[F.n_bsph + pt_record_slot(i, F.n_bbox)] = B.bbox[i].index;
+            if (NEST) {  // record -> object of the dielectric-only lists (behind the tables of the full lists)
+                int *kd = lds_kidx + F.n_bsph + F.n_bbox;
+                for (int i = threadIdx.x; i < F.n_dsph; i += PT_BLOCK) kd[pt_record_slot(i, F.n_dsph)] = B.bsph_diel[i].index;
+                for (int i = threadIdx.x; i < F.n_dbox; i += PT_BLOCK) kd[F.n_dsph + pt_record_slot(i, F.n_dbox)] = B.bbox_diel[i].index;
+            }
         }
         __syncthreads();
     }
@@ -1806,9 +1821,9 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                     trav.live = false;  // a complete answer: whatever walk was pending is obsolete
                 } else {
                     if (WIDE)
-                        scan_broad_narrow_wide<PROF, VERIFY, SPLIT ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
+                        scan_broad_narrow_wide<PROF, VERIFY, (SPLIT || NEST) ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
                     else if (BITMASK)
-                        scan_broad_narrow<PROF, VERIFY, SPLIT ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
+                        scan_broad_narrow<PROF, VERIFY, (SPLIT || NEST) ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
                     else if ((fat = !trav.live && clip.far && !clip.miss && clip.infl * 16.0 > F.scene_bound))
                         scanned = false;  // no walk for this one: the whole wave scans the world for it, below
                     else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
@@ -1864,8 +1879,9 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
         if (active && scanned) {
             // -------------------------------------------------------- shade
             bool do_rr = false;
+            bool nest_exit = false;  // NEST: a dielectric front face was shaded, its exit search comes now
             double attx = 1, atty = 1, attz = 1;
-            if (SPLIT || mode == 0) {
+            if (SPLIT || NEST || mode == 0) {
                 c_seg++;
                 if (STATS) j_seg++;
                 if (best < 0) {
@@ -1897,8 +1913,9 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                     shade_hit<STATS, !SPLIT>(s_obj[best], s_mat, tmax, ox, oy, oz, dx, dy, dz, rs, c_draw, j_draw, finished, termx, termy,
                                              termz, attx, atty, attz, exit_search, exit_mat);
                     if (exit_search) {
-                        mode = 1;
                         c_exit++;
+                        if (NEST) nest_exit = true;
+                        else mode = 1;
                     } else if (!finished) {
                         do_rr = true;
                     }
@@ -1909,6 +1926,43 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 SEC_BEGIN(SEC_EXITPOST)
                 exit_post(s_mat[exit_mat], best, tmax, ox, oy, oz, dx, dy, dz, attx, atty, attz);
                 mode = 0;
+                do_rr = true;
+                SEC_END(SEC_EXITPOST)
+            }
+
+            if (NEST && nest_exit) {
+                // ---------------------------------------------------- the way out of the glass, before roulette (renderer.go:316-371):
+                // the scattered ray against the dielectric objects' own records (as glass_kernel does for the split rounds)
+                SEC_BEGIN(SEC_EXITPOST)
+                const RayD eray{ox, oy, oz, dx, dy, dz};
+                const ProfHooks eph{p_exec, p_lanes, p_cyc, lane, nullptr};
+                int ebest = -1;
+                double etmax = 0;
+                const double ea = dx * dx + dy * dy + dz * dz;
+                const Clip eclip = clip_ray(F, eray, 0.0001);
+                // same guards as the main scan: untamed or far-away rays take the reference's plain loop
+                const bool etame = (ea >= 1e-100) && (ea <= 1e100) && (ptm::f_abs(ox) <= 1e100) && (ptm::f_abs(oy) <= 1e100) &&
+                                   (ptm::f_abs(oz) <= 1e100) && !eclip.far;
+                if (__ballot(!etame) != 0) {
+                    scan_uniform(F, g_obj, eray, 1, ebest, etmax);
+                } else {
+                    constexpr bool WIDE_ = (SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE);
+                    constexpr bool VERIFY_ = (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_WIDE);
+                    const uint32_t all_s = F.n_dsph >= 32 ? 0xffffffffu : ((1u << F.n_dsph) - 1u), all_b = F.n_dbox >= 32 ? 0xffffffffu : ((1u << F.n_dbox) - 1u);
+                    const BroadLists<ConstSphPtr, ConstBoxPtr> BLd{(ConstSphPtr)KA->B.bsph_diel, (ConstBoxPtr)KA->B.bbox_diel, F.n_dsph, F.n_dbox, all_s, all_b, all_s, all_b,
+                                                                   lds_kidx + F.n_bsph + F.n_bbox, lds_kidx + F.n_bsph + F.n_bbox + F.n_dsph};
+                    if (WIDE_) scan_broad_narrow_wide<PROF, VERIFY_, 1>(F, g_obj, BLd, g_pl, s_obj, eray, eclip, 1, ebest, etmax, eph);
+                    else scan_broad_narrow<PROF, VERIFY_, 1>(F, g_obj, BLd, g_pl, s_obj, eray, eclip, 1, ebest, etmax, eph);
+                    if (VERIFY_) {
+                        int best2;
+                        double tmax2;
+                        scan_uniform(F, g_obj, eray, 1, best2, tmax2);
+                        if (ebest != best2 || (ebest >= 0 && !(etmax == tmax2))) c_mismatch++;
+                        ebest = best2;
+                        etmax = tmax2;
+                    }
+                }
+                exit_post(s_mat[exit_mat], ebest, etmax, ox, oy, oz, dx, dy, dz, attx, atty, attz);
                 do_rr = true;
                 SEC_END(SEC_EXITPOST)
             }

@@ -148,6 +148,7 @@ struct Frame {
     bool walk32 = false;     // ... with its traversal pass split into the FP32 walk and the exact pass of pt_walk32.h
     size_t shade_lds_bytes = 0;
     int split_rounds = 0;  // trace + glass pass pairs before the all-in-one pass (0: all-in-one only)
+    int tail_form = 0;     // ptk::FORM_* of the pass behind the split rounds (FORM_NESTED for the bitmask scans, see pt_kernels.h)
     bool has_glass = false;  // some object is dielectric
     int scan = 0;  // ptk::SCAN_* used for this frame
     std::chrono::steady_clock::time_point t0;
@@ -199,6 +200,7 @@ struct pt_ctx {
     int wf_min_lanes = 40; // PTCORE_WF_MIN_LANES: the walk loop of a traversal pass is left for a refill below this many walking lanes
     int wf_sort = 0;       // PTCORE_WF_SORT=1: reorder the paths of a level by direction octant and origin cell
     int split_rounds = 2;  // PTCORE_SPLIT_ROUNDS: trace + glass pass pairs per chunk before the all-in-one pass (bitmask scan only)
+    bool tail_nested = true;  // PTCORE_TAIL=trip: the pass behind the split rounds in the round-1 form (exit search = the lane's next trip) instead of FORM_NESTED
     uint32_t claim = 0;   // jobs per queue claim; 0 = by pass shape (dev_step), PTCORE_CLAIM forces one
     int max_blocks_per_cu = 8;
     int scan_mode = -1;  // -1 = choose by scene size; PTCORE_SCAN=uniform|broad|verify|bvh|verify_bvh forces one
@@ -484,30 +486,35 @@ int32_t validate(const pt_scene *scene, const pt_config *cfg) {
 using TraceFn = void (*)(const TraceArgs);
 
 // The shipping instantiations are <false,false,*,*>; STATS adds per-pixel counters, PROF the section profile.
-// split: the form whose dielectric hits leave for the glass queue (bitmask scan of the reference-sized scenes only).
-TraceFn pick_trace(bool stats, bool prof, int scan, bool split = false) {
+// form (pt_kernels.h): FORM_SPLIT = dielectric hits leave for the glass queue, FORM_NESTED = the pass behind the split rounds (both: the
+// bitmask scans of the reference-sized scenes only), FORM_ALL_IN_ONE = everything else.
+TraceFn pick_trace(bool stats, bool prof, int scan, int form = ptk::FORM_ALL_IN_ONE) {
     using namespace ptk;
     if (prof) {
-        if (scan == SCAN_UNIFORM) return trace_kernel<false, true, SCAN_UNIFORM, false>;
-        if (scan == SCAN_BVH || scan == SCAN_VERIFY_BVH) return trace_kernel<false, true, SCAN_BVH, false>;
-        if (scan == SCAN_BROAD_WIDE || scan == SCAN_VERIFY_WIDE) return trace_kernel<false, true, SCAN_BROAD_WIDE, false>;
-        return split ? trace_kernel<false, true, SCAN_BROAD, true> : trace_kernel<false, true, SCAN_BROAD, false>;
+        if (scan == SCAN_UNIFORM) return trace_kernel<false, true, SCAN_UNIFORM, FORM_ALL_IN_ONE>;
+        if (scan == SCAN_BVH || scan == SCAN_VERIFY_BVH) return trace_kernel<false, true, SCAN_BVH, FORM_ALL_IN_ONE>;
+        if (scan == SCAN_BROAD_WIDE || scan == SCAN_VERIFY_WIDE) return trace_kernel<false, true, SCAN_BROAD_WIDE, FORM_ALL_IN_ONE>;
+        return form == FORM_SPLIT ? trace_kernel<false, true, SCAN_BROAD, FORM_SPLIT>
+               : form == FORM_NESTED ? trace_kernel<false, true, SCAN_BROAD, FORM_NESTED> : trace_kernel<false, true, SCAN_BROAD, FORM_ALL_IN_ONE>;
     }
-    if (split) {
-        if (scan == SCAN_VERIFY) return stats ? trace_kernel<true, false, SCAN_VERIFY, true> : trace_kernel<false, false, SCAN_VERIFY, true>;
-        if (scan == SCAN_BROAD_WIDE) return stats ? trace_kernel<true, false, SCAN_BROAD_WIDE, true> : trace_kernel<false, false, SCAN_BROAD_WIDE, true>;
-        if (scan == SCAN_VERIFY_WIDE) return stats ? trace_kernel<true, false, SCAN_VERIFY_WIDE, true> : trace_kernel<false, false, SCAN_VERIFY_WIDE, true>;
-        return stats ? trace_kernel<true, false, SCAN_BROAD, true> : trace_kernel<false, false, SCAN_BROAD, true>;
+#define PT_PICK(SCAN_, FORM_) (stats ? trace_kernel<true, false, SCAN_, FORM_> : trace_kernel<false, false, SCAN_, FORM_>)
+    if (form != FORM_ALL_IN_ONE) {  // bitmask scans only (trace_form() never asks otherwise)
+        const bool nest = form == FORM_NESTED;
+        if (scan == SCAN_VERIFY) return nest ? PT_PICK(SCAN_VERIFY, FORM_NESTED) : PT_PICK(SCAN_VERIFY, FORM_SPLIT);
+        if (scan == SCAN_BROAD_WIDE) return nest ? PT_PICK(SCAN_BROAD_WIDE, FORM_NESTED) : PT_PICK(SCAN_BROAD_WIDE, FORM_SPLIT);
+        if (scan == SCAN_VERIFY_WIDE) return nest ? PT_PICK(SCAN_VERIFY_WIDE, FORM_NESTED) : PT_PICK(SCAN_VERIFY_WIDE, FORM_SPLIT);
+        return nest ? PT_PICK(SCAN_BROAD, FORM_NESTED) : PT_PICK(SCAN_BROAD, FORM_SPLIT);
     }
     switch (scan) {
-        case SCAN_BROAD: return stats ? trace_kernel<true, false, SCAN_BROAD, false> : trace_kernel<false, false, SCAN_BROAD, false>;
-        case SCAN_VERIFY: return stats ? trace_kernel<true, false, SCAN_VERIFY, false> : trace_kernel<false, false, SCAN_VERIFY, false>;
-        case SCAN_BROAD_WIDE: return stats ? trace_kernel<true, false, SCAN_BROAD_WIDE, false> : trace_kernel<false, false, SCAN_BROAD_WIDE, false>;
-        case SCAN_VERIFY_WIDE: return stats ? trace_kernel<true, false, SCAN_VERIFY_WIDE, false> : trace_kernel<false, false, SCAN_VERIFY_WIDE, false>;
-        case SCAN_BVH: return stats ? trace_kernel<true, false, SCAN_BVH, false> : trace_kernel<false, false, SCAN_BVH, false>;
-        case SCAN_VERIFY_BVH: return stats ? trace_kernel<true, false, SCAN_VERIFY_BVH, false> : trace_kernel<false, false, SCAN_VERIFY_BVH, false>;
-        default: return stats ? trace_kernel<true, false, SCAN_UNIFORM, false> : trace_kernel<false, false, SCAN_UNIFORM, false>;
+        case SCAN_BROAD: return PT_PICK(SCAN_BROAD, FORM_ALL_IN_ONE);
+        case SCAN_VERIFY: return PT_PICK(SCAN_VERIFY, FORM_ALL_IN_ONE);
+        case SCAN_BROAD_WIDE: return PT_PICK(SCAN_BROAD_WIDE, FORM_ALL_IN_ONE);
+        case SCAN_VERIFY_WIDE: return PT_PICK(SCAN_VERIFY_WIDE, FORM_ALL_IN_ONE);
+        case SCAN_BVH: return PT_PICK(SCAN_BVH, FORM_ALL_IN_ONE);
+        case SCAN_VERIFY_BVH: return PT_PICK(SCAN_VERIFY_BVH, FORM_ALL_IN_ONE);
+        default: return PT_PICK(SCAN_UNIFORM, FORM_ALL_IN_ONE);
     }
+#undef PT_PICK
 }
 
 using GlassFn = void (*)(const ptk::GlassArgs);
@@ -632,7 +639,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
     // occupancy of the kernels of this frame for the scene's LDS footprint (before the buffers: the queue slack depends on it)
     const size_t lds = fr.lds_bytes;
     int nb = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan), PT_BLOCK, lds));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, fr.tail_form), PT_BLOCK, lds));
     d.blocks_per_cu = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
     d.blocks_per_cu_split = d.blocks_per_cu;
     d.blocks_per_cu_glass = 1;
@@ -648,7 +655,7 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         }
     }
     if (fr.split_rounds > 0) {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, true), PT_BLOCK, lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, ptk::FORM_SPLIT), PT_BLOCK, lds));
         d.blocks_per_cu_split = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_glass(fr.stats_on, fr.scan), PT_BLOCK, fr.glass_lds_bytes));
         d.blocks_per_cu_glass = std::max(1, std::min(nb, PT_GLASS_MAX_BLOCKS_PER_CU));
@@ -1044,7 +1051,8 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
             d.trace_is_split[d.n_trace] = split ? 1 : 0;
             EventPair &e = d.ev_trace[d.n_trace++];
             HIP_TRY(hipEventRecord(e.a, d.stream));
-            hipLaunchKernelGGL(pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, split), dim3(grid), dim3(PT_BLOCK), lds, d.stream, A);
+            hipLaunchKernelGGL(pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, split ? (int)ptk::FORM_SPLIT : rounds > 0 ? fr.tail_form : (int)ptk::FORM_ALL_IN_ONE),
+                               dim3(grid), dim3(PT_BLOCK), lds, d.stream, A);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(e.b, d.stream));
             if (pass_log) {  // PTCORE_DEBUG_PASS_LOG=1 (diagnostics): what every trace pass did; serialises the stream
@@ -1262,7 +1270,7 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     // groups of 32; more -> BVH.  PTCORE_SCAN overrides.
     int scan = ctx->scan_mode;
     // the LDS copy of the world (objects + materials + record indices) must leave room for five blocks per CU
-    const size_t world_lds = sd.world.size() * sizeof(DevObj) + sd.mats.size() * sizeof(DevMat) + (sd.bsph.size() + sd.bbox.size()) * sizeof(int);
+    const size_t world_lds = sd.world.size() * sizeof(DevObj) + sd.mats.size() * sizeof(DevMat) + (sd.bsph.size() + sd.bbox.size() + sd.bsph_diel.size() + sd.bbox_diel.size()) * sizeof(int);
     const bool wide_ok = F.broad_ok == 2 && world_lds <= 30 * 1024;
     if (scan < 0) scan = F.broad_ok == 1 ? ptk::SCAN_BROAD : wide_ok ? ptk::SCAN_BROAD_WIDE : ptk::SCAN_BVH;
     if ((scan == ptk::SCAN_BROAD || scan == ptk::SCAN_VERIFY) && F.broad_ok != 1) {
@@ -1384,7 +1392,7 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
         F.bvh_lds_nodes = (int32_t)std::min<size_t>((lds_budget - stack_bytes) / sizeof(BvhNode), (size_t)F.bvh_main_nodes);
     sd.lds_bytes = big ? stack_bytes + (size_t)F.bvh_lds_nodes * sizeof(BvhNode)
                        : (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
-                             (size_t)(sd.bsph.size() + sd.bbox.size()) * sizeof(int);
+                             (size_t)(sd.bsph.size() + sd.bbox.size() + sd.bsph_diel.size() + sd.bbox_diel.size()) * sizeof(int);  // (+ the dielectric-only tables of FORM_NESTED)
     sd.glass_lds_bytes = (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
                          (size_t)(sd.bsph_diel.size() + sd.bbox_diel.size()) * sizeof(int);
     // PTCORE_BVH_LDS_PAD=<bytes>: unused LDS on top of the BVH plan (occupancy experiments: 4 blocks per CU fit 40 KiB each)
@@ -1419,13 +1427,14 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     if ((sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY || sd.scan == ptk::SCAN_BROAD_WIDE || sd.scan == ptk::SCAN_VERIFY_WIDE) &&
         cfg->max_depth > 0)
         fr.split_rounds = fr.has_glass ? std::max(0, std::min(ctx->split_rounds, cfg->max_depth)) : (ctx->split_rounds > 0 ? 1 : 0);
+    fr.tail_form = (fr.split_rounds > 0 && fr.has_glass && ctx->tail_nested && !ctx->profile_sections) ? ptk::FORM_NESTED : ptk::FORM_ALL_IN_ONE;
     {  // the wavefront form: on request (PTCORE_PIPELINE=wavefront), for the scans that have a pass form (bitmask, BVH).
        // Measured slower than the all-in-one loop in every regime, so it is the A/B, not the default.
         const bool bvh = sd.scan == ptk::SCAN_BVH || sd.scan == ptk::SCAN_VERIFY_BVH;
         const bool flat = sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY;
         fr.wavefront = !ctx->profile_sections && ((ctx->pipeline == 1 && (bvh || flat)) || (ctx->pipeline == 2 && bvh));
         fr.walk32 = fr.wavefront && ctx->pipeline == 2;
-        if (fr.wavefront) fr.split_rounds = 0;
+        if (fr.wavefront) { fr.split_rounds = 0; fr.tail_form = ptk::FORM_ALL_IN_ONE; }
         fr.shade_lds_bytes = (size_t)sd.Fs.nmat * sizeof(DevMat) + (sd.Fs.world_in_lds ? (size_t)sd.Fs.nobj * sizeof(DevObj) : 0);
     }
     fr.cam = new_camera(scene->camera, cfg->width, cfg->height);
@@ -1511,6 +1520,7 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
     }
     if (const char *e = std::getenv("PTCORE_PROFILE")) ctx->profile_sections = std::atoi(e) != 0;
     if (const char *e = std::getenv("PTCORE_SPLIT_ROUNDS")) ctx->split_rounds = std::max(0, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("PTCORE_TAIL")) ctx->tail_nested = std::strcmp(e, "trip") != 0;
     if (const char *e = std::getenv("PTCORE_PIPELINE")) ctx->pipeline = !std::strcmp(e, "wavefront") ? 1 : !std::strcmp(e, "walk32") ? 2 : !std::strcmp(e, "mega") ? 0 : -1;
     if (const char *e = std::getenv("PTCORE_WF_MIN_LANES")) ctx->wf_min_lanes = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("PTCORE_WF_SORT")) ctx->wf_sort = std::atoi(e);

@@ -21,7 +21,8 @@ out = {"tag": tag}
 def klass(name: str):
     m = re.search(r"trace_kernel<(\w+), (\w+), (\d+), (\w+)>", name)
     if m:
-        return "trace_split" if m.group(4) == "true" else "trace_allinone"
+        # 4th parameter: FORM (0 all-in-one, 1 split, 2 nested exit search); a bool before round 4
+        return "trace_split" if m.group(4) in ("true", "1") else "trace_nested" if m.group(4) == "2" else "trace_allinone"
     for k in ("glass_kernel", "raygen_lens_kernel", "raygen_kernel", "resolve_kernel", "wf_", "untile_kernel"):
         if k in name:
             return k.replace("_kernel", "")
@@ -72,7 +73,7 @@ traffic = {}
 b = out.get("bench_under_pmc")
 if isinstance(b, dict) and "roofline" in b:
     name = b["roofline"]["kernel"]
-    k = "trace_split" if name.endswith("true>") else "trace_allinone"
+    k = "trace_split" if name.endswith(("true>", ",1>")) else "trace_allinone"
     if k in derived and derived[k]["hbm_fetch_bytes_x2"]:
         alg = b["roofline"]["alg_bytes_per_launch"] * b["roofline"]["launches_per_step"] * b["steps"]
         hbm = derived[k]["hbm_fetch_bytes_x2"] + derived[k]["hbm_write_bytes"]
