@@ -1637,7 +1637,8 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
 
     // work items of this pass: continuation entries [0, n_cont), then fresh jobs [n_cont, n_cont + F.fresh)
     // (only the scans that have a split form ever see continuation entries)
-    constexpr bool CONT = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY || SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE);
+    // (... and, since round 4, the BVH scans: primary_bvh_kernel -- pt_primary.h -- hands every path over through the queue)
+    constexpr bool CONT = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY || SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE || BIG);
     typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
     const uint32_t n_cont_raw = CONT ? *(ConstU32Ptr)(B.cont_in) : 0u;
     const uint32_t n_cont = n_cont_raw < B.cont.cap ? n_cont_raw : B.cont.cap;

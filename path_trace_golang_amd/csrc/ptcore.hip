@@ -27,6 +27,7 @@
 #include "pt_kernels.h"
 #include "pt_wavefront.h"
 #include "pt_walk32.h"
+#include "pt_primary.h"
 #include "pt_math.h"
 
 using namespace ptd;
@@ -127,7 +128,7 @@ struct Device {
     int32_t nlocal = 0;
     uint32_t nslots = 0;
     bool acc_started = false;
-    int blocks_per_cu = 0, blocks_per_cu_split = 0, blocks_per_cu_glass = 0;
+    int blocks_per_cu = 0, blocks_per_cu_split = 0, blocks_per_cu_glass = 0, blocks_per_cu_primary = 0;
     uint64_t scene_gen = 0;  // SceneData generation resident on this device (0 = none)
 };
 
@@ -150,6 +151,7 @@ struct Frame {
     int split_rounds = 0;  // trace + glass pass pairs before the all-in-one pass (0: all-in-one only)
     int tail_form = 0;     // ptk::FORM_* of the pass behind the split rounds (FORM_NESTED for the bitmask scans, see pt_kernels.h)
     bool has_glass = false;  // some object is dielectric
+    bool primary_pass = false;  // BVH scans: the first segment of every path by primary_bvh_kernel (pt_primary.h), the rest through the continuation queue
     int scan = 0;  // ptk::SCAN_* used for this frame
     std::chrono::steady_clock::time_point t0;
 };
@@ -200,6 +202,7 @@ struct pt_ctx {
     int wf_min_lanes = 40; // PTCORE_WF_MIN_LANES: the walk loop of a traversal pass is left for a refill below this many walking lanes
     int wf_sort = 0;       // PTCORE_WF_SORT=1: reorder the paths of a level by direction octant and origin cell
     int split_rounds = 2;  // PTCORE_SPLIT_ROUNDS: trace + glass pass pairs per chunk before the all-in-one pass (bitmask scan only)
+    bool primary_coop = true;  // PTCORE_PRIMARY=lane: BVH scenes without the wave-cooperative primary pass (the round-3 loop)
     bool tail_nested = true;  // PTCORE_TAIL=trip: the pass behind the split rounds in the round-1 form (exit search = the lane's next trip) instead of FORM_NESTED
     uint32_t claim = 0;   // jobs per queue claim; 0 = by pass shape (dev_step), PTCORE_CLAIM forces one
     int max_blocks_per_cu = 8;
@@ -517,6 +520,12 @@ TraceFn pick_trace(bool stats, bool prof, int scan, int form = ptk::FORM_ALL_IN_
 #undef PT_PICK
 }
 
+TraceFn pick_primary(bool stats, int scan) {
+    using namespace ptk;
+    if (scan == SCAN_VERIFY_BVH) return stats ? primary_bvh_kernel<true, true> : primary_bvh_kernel<false, true>;
+    return stats ? primary_bvh_kernel<true, false> : primary_bvh_kernel<false, false>;
+}
+
 using GlassFn = void (*)(const ptk::GlassArgs);
 GlassFn pick_glass(bool stats, int scan) {
     using namespace ptk;
@@ -556,6 +565,8 @@ size_t queue_slack(const pt_ctx *ctx, const Device &d, size_t njobs_max) {
     size_t writer_blocks;
     if (fr.wavefront)
         writer_blocks = 2 * std::min<size_t>((size_t)d.num_cu * PT_WF_PASS_BLOCKS_PER_CU, grid_cap);
+    else if (fr.primary_pass)  // continuation queue <- primary_bvh_kernel (num_cu x blocks_per_cu_primary blocks, windows of PT_CONT_BLOCK)
+        writer_blocks = std::min<size_t>((size_t)d.num_cu * (size_t)d.blocks_per_cu_primary, grid_cap);
     else
         writer_blocks = std::min<size_t>((size_t)d.num_cu * (size_t)std::max(d.blocks_per_cu_split, d.blocks_per_cu_glass), grid_cap);
     return writer_blocks * (PT_BLOCK / PT_WAVE) * PT_CONT_BLOCK;
@@ -654,6 +665,10 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
             if (std::getenv("PTCORE_VERBOSE")) std::fprintf(stderr, "ptcore: walk32: %d blocks per CU for the FP32 walk, %d for the FP64 traversal of the slow list\n", d.blocks_per_cu_walk, d.blocks_per_cu_wf);
         }
     }
+    if (fr.primary_pass) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_primary(fr.stats_on, fr.scan), PT_BLOCK, 0));
+        d.blocks_per_cu_primary = std::max(1, std::min(nb, 8));
+    }
     if (fr.split_rounds > 0) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, ptk::FORM_SPLIT), PT_BLOCK, lds));
         d.blocks_per_cu_split = std::max(1, std::min(nb, ctx->max_blocks_per_cu));
@@ -662,8 +677,8 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
     }
     // per-pass buffers: 90 B per job (radiance record, primary ray, stream state, draw count; + 8 B with pixel stats) and, for the
     // forms that park paths in HBM, two or three path-state queues
-    const bool queues = fr.wavefront || (fr.split_rounds > 0 && fr.has_glass);
-    const size_t nqueues = !queues ? 0 : fr.wavefront ? 3 : 2;
+    const bool queues = fr.wavefront || (fr.split_rounds > 0 && fr.has_glass) || fr.primary_pass;
+    const size_t nqueues = !queues ? 0 : fr.wavefront ? 3 : fr.primary_pass ? 1 : 2;  // (the primary pass of the BVH path fills the continuation queue only)
     const size_t qplanes = fr.stats_on ? 6 : 4;
     const size_t qentry = 10 * sizeof(double) + sizeof(unsigned long long) + qplanes * sizeof(uint32_t);
     const size_t job_bytes = 4 * sizeof(double) + 6 * sizeof(double) + sizeof(unsigned long long) + sizeof(uint16_t) +
@@ -714,11 +729,13 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
             // PTCORE_DEBUG_QUEUE_CAP=<entries> (tests only): queues too small for the frame, to show that an overflow fails the
             // frame with PT_ERR_STATE instead of writing outside them
             if (const char *dbg = std::getenv("PTCORE_DEBUG_QUEUE_CAP")) qcap = (size_t)std::max(64L, std::atol(dbg));
-            if (e == hipSuccess) e = d.gq_d.reserve(10 * qcap);
+            if (!fr.primary_pass) {
+                if (e == hipSuccess) e = d.gq_d.reserve(10 * qcap);
+                if (e == hipSuccess) e = d.gq_rs.reserve(qcap);
+                if (e == hipSuccess) e = d.gq_u32.reserve(qplanes * qcap);
+            }
             if (e == hipSuccess) e = d.cq_d.reserve(10 * qcap);
-            if (e == hipSuccess) e = d.gq_rs.reserve(qcap);
             if (e == hipSuccess) e = d.cq_rs.reserve(qcap);
-            if (e == hipSuccess) e = d.gq_u32.reserve(qplanes * qcap);
             if (e == hipSuccess) e = d.cq_u32.reserve(qplanes * qcap);
             if (fr.wavefront) {
                 if (e == hipSuccess) e = d.xq_d.reserve(10 * qcap);
@@ -986,7 +1003,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     B.prof = ctx->profile_sections ? d.prof.p : nullptr;
 
     const int rounds = fr.split_rounds;
-    if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + (size_t)rounds + 1)) return rc;
+    if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + (size_t)rounds + 2)) return rc;
     if (int32_t rc = dev_events(d, d.ev_glass, d.n_glass + (size_t)rounds + 1)) return rc;
     if (int32_t rc = dev_events(d, d.ev_resolve, d.n_resolve + 1)) return rc;
     if (!d.first_recorded) {
@@ -1001,7 +1018,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     B.bbox_diel = d.bbox_diel.p;
     std::memset(&B.glass, 0, sizeof B.glass);
     std::memset(&B.cont, 0, sizeof B.cont);
-    if (rounds > 0) {
+    if (rounds > 0 || fr.primary_pass) {
         const size_t cap = d.q_cap;
         auto bind = [&](PathQueue &q, DevBuf<double> &qd, DevBuf<unsigned long long> &qrs, DevBuf<uint32_t> &qu) {
             q.d = qd.p;
@@ -1014,7 +1031,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
             q.jdraw = fr.stats_on ? qu.p + 5 * cap : nullptr;
             q.cap = (uint32_t)cap;
         };
-        bind(B.glass, d.gq_d, d.gq_rs, d.gq_u32);
+        if (rounds > 0) bind(B.glass, d.gq_d, d.gq_rs, d.gq_u32);
         bind(B.cont, d.cq_d, d.cq_rs, d.cq_u32);
         B.glass.count = qw + 1;
     }
@@ -1051,7 +1068,7 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
             d.trace_is_split[d.n_trace] = split ? 1 : 0;
             EventPair &e = d.ev_trace[d.n_trace++];
             HIP_TRY(hipEventRecord(e.a, d.stream));
-            hipLaunchKernelGGL(pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, split ? (int)ptk::FORM_SPLIT : rounds > 0 ? fr.tail_form : (int)ptk::FORM_ALL_IN_ONE),
+            hipLaunchKernelGGL(pick_trace(fr.stats_on, ctx->profile_sections, fr.scan, split ? (int)ptk::FORM_SPLIT : fr.tail_form),
                                dim3(grid), dim3(PT_BLOCK), lds, d.stream, A);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(e.b, d.stream));
@@ -1069,7 +1086,36 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
             }
             return PT_OK;
         };
-        if (rounds == 0) {
+        if (fr.primary_pass) {
+            // BVH scenes: the first segment of every path by the wave-cooperative kernel (pt_primary.h); what goes on -- and what that
+            // kernel is not meant for, unshaded -- reaches the per-lane loop through the continuation queue
+            B.cont_in = qw + 2;
+            B.cont.count = qw + 2;
+            TraceArgs A;
+            A.F = F;
+            A.F.fresh = 0u;
+            A.sky = fr.sky;
+            A.B = B;
+            const uint32_t pgrid = std::max(1u, std::min((uint32_t)(d.num_cu * d.blocks_per_cu_primary), (F.njobs + PT_BLOCK - 1) / PT_BLOCK));  // same bound as queue_slack()
+            if (d.trace_is_split.size() <= d.n_trace) d.trace_is_split.resize(d.n_trace + 1);
+            d.trace_is_split[d.n_trace] = 0;
+            EventPair &e = d.ev_trace[d.n_trace++];
+            HIP_TRY(hipEventRecord(e.a, d.stream));
+            hipLaunchKernelGGL(pick_primary(fr.stats_on, fr.scan), dim3(pgrid), dim3(PT_BLOCK), 0, d.stream, A);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(e.b, d.stream));
+            if (pass_log) {
+                HIP_TRY(hipStreamSynchronize(d.stream));
+                unsigned long long c[48];
+                HIP_TRY(hipMemcpy(c, d.counters.p, sizeof c, hipMemcpyDeviceToHost));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+                std::fprintf(stderr, "ptcore pass: primary<wave> grid %u  %.3f ms  segments shaded %llu  handed on %llu  wave-level node visits %llu over %llu blocks of 64 jobs (%llu more handed over unwalked)\n",
+                             pgrid, ms, c[0] - d.pass_log_prev[0], c[6], c[40], c[41], c[42]);
+                std::memcpy(d.pass_log_prev, c, sizeof d.pass_log_prev);
+            }
+            if (int32_t rc = launch_trace(false, false)) return rc;
+        } else if (rounds == 0) {
             if (int32_t rc = launch_trace(false, true)) return rc;
         } else {
             // Split passes: trace (dielectric hits -> glass queue), glass (-> continuation queue), `rounds` times; what is
@@ -1427,7 +1473,10 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     if ((sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY || sd.scan == ptk::SCAN_BROAD_WIDE || sd.scan == ptk::SCAN_VERIFY_WIDE) &&
         cfg->max_depth > 0)
         fr.split_rounds = fr.has_glass ? std::max(0, std::min(ctx->split_rounds, cfg->max_depth)) : (ctx->split_rounds > 0 ? 1 : 0);
-    fr.tail_form = (fr.split_rounds > 0 && fr.has_glass && ctx->tail_nested && !ctx->profile_sections) ? ptk::FORM_NESTED : ptk::FORM_ALL_IN_ONE;
+    {
+        const bool bitmask = sd.scan == ptk::SCAN_BROAD || sd.scan == ptk::SCAN_VERIFY || sd.scan == ptk::SCAN_BROAD_WIDE || sd.scan == ptk::SCAN_VERIFY_WIDE;
+        fr.tail_form = (bitmask && fr.has_glass && ctx->tail_nested && !ctx->profile_sections) ? ptk::FORM_NESTED : ptk::FORM_ALL_IN_ONE;
+    }
     {  // the wavefront form: on request (PTCORE_PIPELINE=wavefront), for the scans that have a pass form (bitmask, BVH).
        // Measured slower than the all-in-one loop in every regime, so it is the A/B, not the default.
         const bool bvh = sd.scan == ptk::SCAN_BVH || sd.scan == ptk::SCAN_VERIFY_BVH;
@@ -1435,6 +1484,7 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
         fr.wavefront = !ctx->profile_sections && ((ctx->pipeline == 1 && (bvh || flat)) || (ctx->pipeline == 2 && bvh));
         fr.walk32 = fr.wavefront && ctx->pipeline == 2;
         if (fr.wavefront) { fr.split_rounds = 0; fr.tail_form = ptk::FORM_ALL_IN_ONE; }
+        fr.primary_pass = bvh && !fr.wavefront && !ctx->profile_sections && ctx->primary_coop && sd.Fs.bvh_root >= 0;
         fr.shade_lds_bytes = (size_t)sd.Fs.nmat * sizeof(DevMat) + (sd.Fs.world_in_lds ? (size_t)sd.Fs.nobj * sizeof(DevObj) : 0);
     }
     fr.cam = new_camera(scene->camera, cfg->width, cfg->height);
@@ -1457,7 +1507,7 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     uint32_t chunk = cfg->spp_chunk > 0 ? (uint32_t)cfg->spp_chunk : 0;
     const uint32_t slots = std::max(1u, max_slots);
     // per job: 32 B radiance record + 58 B primary ray, and with split passes two path-state queues of 100 B per entry
-    const size_t job_bytes = 90 + (fr.wavefront ? 330 + (fr.walk32 ? 4 * (PT_CAND_MAX + 2) : 0) : fr.split_rounds > 0 && fr.has_glass ? 220 : 0);
+    const size_t job_bytes = 90 + (fr.wavefront ? 330 + (fr.walk32 ? 4 * (PT_CAND_MAX + 2) : 0) : fr.split_rounds > 0 && fr.has_glass ? 220 : fr.primary_pass ? 110 : 0);
     if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * job_bytes));
     chunk = std::min<uint32_t>(chunk, (uint32_t)std::max(1, cfg->samples_per_px));
     chunk = std::min<uint32_t>(chunk, std::max(1u, 0x7fffffffu / slots));
@@ -1521,6 +1571,7 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
     if (const char *e = std::getenv("PTCORE_PROFILE")) ctx->profile_sections = std::atoi(e) != 0;
     if (const char *e = std::getenv("PTCORE_SPLIT_ROUNDS")) ctx->split_rounds = std::max(0, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("PTCORE_TAIL")) ctx->tail_nested = std::strcmp(e, "trip") != 0;
+    if (const char *e = std::getenv("PTCORE_PRIMARY")) ctx->primary_coop = std::strcmp(e, "lane") != 0;
     if (const char *e = std::getenv("PTCORE_PIPELINE")) ctx->pipeline = !std::strcmp(e, "wavefront") ? 1 : !std::strcmp(e, "walk32") ? 2 : !std::strcmp(e, "mega") ? 0 : -1;
     if (const char *e = std::getenv("PTCORE_WF_MIN_LANES")) ctx->wf_min_lanes = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("PTCORE_WF_SORT")) ctx->wf_sort = std::atoi(e);
