@@ -1695,14 +1695,19 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
         const uint64_t need = __ballot(!active);
         if (need != 0) {
             if (cur >= end && !exhausted) {
+                // (Round 4 tried guided claims -- a claim's size falling with what is left of the queue, 1 / (4 x waves) of it down to one
+                // row of 64, so that the waves of a launch end together: C4 533.3 against 529.8 ms per frame at 4 passes, 559.1 against
+                // 551.2 at 13, profiles/r04_guided_claims_ab.txt.  A claim is an atomic round trip during which the wave's idle lanes
+                // wait; many small ones cost more than the even finish gives.  Round 2 had the same answer for a fixed tail of 64-job claims.)
+                const uint32_t want = F.claim;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(KA->B.queue, F.claim);
+                if (lane == 0) base = atomicAdd(KA->B.queue, want);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= n_items) {
                     exhausted = true;
                 } else {
                     cur = base;
-                    end = (n_items - base < F.claim) ? n_items : base + F.claim;
+                    end = (n_items - base < want) ? n_items : base + want;
                 }
             }
             const uint32_t avail = end - cur;

@@ -149,6 +149,7 @@ struct Frame {
     bool walk32 = false;     // ... with its traversal pass split into the FP32 walk and the exact pass of pt_walk32.h
     size_t shade_lds_bytes = 0;
     int split_rounds = 0;  // trace + glass pass pairs before the all-in-one pass (0: all-in-one only)
+    size_t budget_bytes = 0;  // job-buffer budget of this frame (pt_ctx::l_budget_bytes, or the grown one)
     int tail_form = 0;     // ptk::FORM_* of the pass behind the split rounds (FORM_NESTED for the bitmask scans, see pt_kernels.h)
     bool has_glass = false;  // some object is dielectric
     bool primary_pass = false;  // BVH scans: the first segment of every path by primary_bvh_kernel (pt_primary.h), the rest through the continuation queue
@@ -198,6 +199,14 @@ struct pt_ctx {
     DevBuf<double> f_accum;
     DevBuf<uint32_t> f_seg, f_draw;
     size_t l_budget_bytes = (size_t)48 << 30;  // per-chunk job buffers (radiance, primary rays, path-state queues): a sixth of the 288 GB
+    // A context that renders frame after frame of one shape (a UI, an animation: gpu.go:2534-2546 is called once per frame) grows its
+    // job buffers by itself from the second such frame on, to the size bench.py asks for explicitly (4 instead of 13 passes per
+    // 1080p x 1024-spp frame: -4.5 % time per frame), provided the device has that much free: a one-shot render keeps the small set-up.
+    // Off when PTCORE_L_BUDGET_MB names a size, or with PTCORE_AUTO_GROW=0.
+    size_t grown_budget_bytes = (size_t)160 << 30;
+    bool auto_grow = true;
+    int32_t last_w = 0, last_h = 0, last_spp = 0;  // the shape of the previous frame of this context
+    bool grown = false;
     int pipeline = -1;     // PTCORE_PIPELINE=mega|wavefront|walk32 (default: by scene, see frame_open)
     int wf_min_lanes = 40; // PTCORE_WF_MIN_LANES: the walk loop of a traversal pass is left for a refill below this many walking lanes
     int wf_sort = 0;       // PTCORE_WF_SORT=1: reorder the paths of a level by direction octant and origin cell
@@ -572,6 +581,13 @@ size_t queue_slack(const pt_ctx *ctx, const Device &d, size_t njobs_max) {
     return writer_blocks * (PT_BLOCK / PT_WAVE) * PT_CONT_BLOCK;
 }
 
+// bytes of job buffers a device holds right now
+size_t dev_held_bytes(const Device &d) {
+    return d.L.cap * sizeof(double) + d.ray.cap * sizeof(double) + d.ray_rng.cap * 8 + d.ray_ndraw.cap * 2 + (d.job_seg.cap + d.job_draw.cap) * 4 +
+           (d.gq_d.cap + d.cq_d.cap + d.xq_d.cap) * sizeof(double) + (d.gq_rs.cap + d.cq_rs.cap + d.xq_rs.cap) * 8 +
+           (d.gq_u32.cap + d.cq_u32.cap + d.xq_u32.cap + d.wf_perm.cap + d.wf_key.cap + d.cand_ids.cap + d.cand_n.cap + d.slow_list.cap) * 4;
+}
+
 // the samples per pass were chosen from the buffer budget (not forced by pt_config.spp_chunk)
 bool cfg_chunk_free(const Frame &fr) { return fr.cfg.spp_chunk <= 0; }
 
@@ -689,18 +705,14 @@ int32_t dev_begin(pt_ctx *ctx, Device &d, const pt_shard &shard, hipStream_t str
         return nj * job_bytes + nqueues * queue_cap(nj) * qentry + (fr.wavefront && ctx->wf_sort ? 2 * queue_cap(nj) * sizeof(uint32_t) : 0) +
                (fr.walk32 ? (PT_CAND_MAX + 2) * queue_cap(nj) * sizeof(uint32_t) : 0);
     };
-    auto held_bytes = [&]() {
-        return d.L.cap * sizeof(double) + d.ray.cap * sizeof(double) + d.ray_rng.cap * 8 + d.ray_ndraw.cap * 2 + (d.job_seg.cap + d.job_draw.cap) * 4 +
-               (d.gq_d.cap + d.cq_d.cap + d.xq_d.cap) * sizeof(double) + (d.gq_rs.cap + d.cq_rs.cap + d.xq_rs.cap) * 8 +
-               (d.gq_u32.cap + d.cq_u32.cap + d.xq_u32.cap + d.wf_perm.cap + d.wf_key.cap + d.cand_ids.cap + d.cand_n.cap + d.slow_list.cap) * 4;
-    };
+    auto held_bytes = [&]() { return dev_held_bytes(d); };
     // The budget covers everything a pass holds, the window slack of the queues included: when the queues push the total over it,
     // the samples per pass shrink (a frame is cut into more passes; pixels do not depend on that).
-    if (cfg_chunk_free(fr) && need_bytes(fr.chunk) > ctx->l_budget_bytes) {
+    if (cfg_chunk_free(fr) && need_bytes(fr.chunk) > fr.budget_bytes) {
         const size_t fixed = need_bytes(1) > (size_t)ns * (job_bytes + nqueues * qentry) ? need_bytes(1) - (size_t)ns * (job_bytes + nqueues * qentry) : 0;
         const size_t per = (size_t)ns * (job_bytes + nqueues * qentry);
-        fr.chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes > fixed ? (ctx->l_budget_bytes - fixed) / per : 1);
-        while (fr.chunk > 1 && need_bytes(fr.chunk) > ctx->l_budget_bytes) fr.chunk -= std::max(1u, fr.chunk / 64u);
+        fr.chunk = (uint32_t)std::max<size_t>(1, fr.budget_bytes > fixed ? (fr.budget_bytes - fixed) / per : 1);
+        while (fr.chunk > 1 && need_bytes(fr.chunk) > fr.budget_bytes) fr.chunk -= std::max(1u, fr.chunk / 64u);
         balance_chunk(fr);
     }
     // A device that once could not give the budget keeps the size that fitted (trying the full budget again on every frame costs
@@ -1508,7 +1520,22 @@ int32_t frame_open(pt_ctx *ctx, const pt_scene *scene, const pt_config *cfg, uin
     const uint32_t slots = std::max(1u, max_slots);
     // per job: 32 B radiance record + 58 B primary ray, and with split passes two path-state queues of 100 B per entry
     const size_t job_bytes = 90 + (fr.wavefront ? 330 + (fr.walk32 ? 4 * (PT_CAND_MAX + 2) : 0) : fr.split_rounds > 0 && fr.has_glass ? 220 : fr.primary_pass ? 110 : 0);
-    if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, ctx->l_budget_bytes / ((size_t)slots * job_bytes));
+    fr.budget_bytes = ctx->l_budget_bytes;
+    if (ctx->auto_grow && ctx->grown_budget_bytes > fr.budget_bytes && !ctx->devs.empty()) {
+        const bool same_shape = cfg->width == ctx->last_w && cfg->height == ctx->last_h && cfg->samples_per_px == ctx->last_spp;
+        if (same_shape && !ctx->grown && (size_t)slots * job_bytes * (size_t)std::max(1, cfg->samples_per_px) > fr.budget_bytes) {
+            // the second frame of this shape, and it takes more than one pass: is the room there?  (free memory + what this context
+            // already holds must cover the grown size with a tenth to spare, on the first device -- the others are its twins)
+            size_t free_b = 0, total_b = 0;
+            if (hipSetDevice(ctx->devs[0].ordinal) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                free_b + dev_held_bytes(ctx->devs[0]) >= ctx->grown_budget_bytes + ctx->grown_budget_bytes / 10)
+                ctx->grown = true;
+            (void)hipGetLastError();
+        }
+        if (ctx->grown && same_shape) fr.budget_bytes = ctx->grown_budget_bytes;
+    }
+    ctx->last_w = cfg->width; ctx->last_h = cfg->height; ctx->last_spp = cfg->samples_per_px;
+    if (chunk == 0) chunk = (uint32_t)std::max<size_t>(1, fr.budget_bytes / ((size_t)slots * job_bytes));
     chunk = std::min<uint32_t>(chunk, (uint32_t)std::max(1, cfg->samples_per_px));
     chunk = std::min<uint32_t>(chunk, std::max(1u, 0x7fffffffu / slots));
     fr.chunk = chunk;
@@ -1553,8 +1580,9 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
     pt_ctx *ctx = new pt_ctx();
     if (const char *e = std::getenv("PTCORE_L_BUDGET_MB")) {
         long mb = std::atol(e);
-        if (mb > 0) ctx->l_budget_bytes = (size_t)mb << 20;
+        if (mb > 0) { ctx->l_budget_bytes = (size_t)mb << 20; ctx->auto_grow = false; }
     }
+    if (const char *e = std::getenv("PTCORE_AUTO_GROW")) ctx->auto_grow = std::atoi(e) != 0;
     if (const char *e = std::getenv("PTCORE_CLAIM")) {
         long c = std::atol(e);
         if (c >= 64 && c % 64 == 0) ctx->claim = (uint32_t)c;

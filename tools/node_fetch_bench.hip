@@ -11,8 +11,12 @@
 #include <cstdint>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 struct alignas(128) Node { uint32_t w[32]; };
-template <int LOADS>
+// SCATTER (round 4): the next index also depends on the step and the thread, so that the lanes do not all fall into the one
+// short cycle a fixed random mapping of the table has (chase<*, false> on a table of any size ends up L2-resident after ~1000
+// steps: profiles/r04_n3_summary.json, fetch_size_control) -- every visit is then an independent random record of the table.
+template <int LOADS, bool SCATTER = false>
 __global__ __launch_bounds__(256) void chase(const Node *__restrict__ t, uint32_t mask, int steps, int active_lanes, uint32_t *out) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u & mask;
     uint32_t acc = 0;
     if ((int)(threadIdx.x & 63) < active_lanes) {
@@ -26,6 +30,7 @@ __global__ __launch_bounds__(256) void chase(const Node *__restrict__ t, uint32_
             }
             acc += x;
             idx = (a.x + (x & 1u)) & mask;  // the next node comes out of this one
+            if (SCATTER) idx = (idx ^ ((uint32_t)s * 0x9E3779B9u) ^ (tid * 0x85EBCA6Bu)) & mask;
         }
     }
     if (acc == 0x12345678u) out[0] = acc;
@@ -57,6 +62,29 @@ int main() {
             printf("%s  {\"table_mib\": %zu, \"waves_per_simd\": %d, \"loads_per_visit\": %d, \"lanes\": %d, \"ms\": %.3f, \"g_visits_per_s\": %.1f, \"wave_visit_ns\": %.0f}",
                    first ? "" : ",\n", n * 128 >> 20, waves, loads, lanes, ms, visits / ms * 1e-6, ms * 1e6 / steps);
             first = false;
+        }
+        CHECK(hipFree(d));
+    }
+    if (getenv("NODE_FETCH_SCATTER")) {  // independent random records of a table far beyond L2 and the Infinity Cache
+        size_t n = (size_t)1 << 24;  // 2 GiB
+        std::vector<Node> h(n);
+        uint64_t s = 88172645463325252ull;
+        for (size_t i = 0; i < n; i++) for (int k = 0; k < 32; k += 4) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i].w[k] = (uint32_t)(s >> 16); }
+        Node *d; CHECK(hipMalloc(&d, n * sizeof(Node)));
+        CHECK(hipMemcpy(d, h.data(), n * sizeof(Node), hipMemcpyHostToDevice));
+        for (int loads : {7, 3}) {
+            const int waves = 4, lanes = 64, blocks = ncu * waves, steps = 500;
+            hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+            for (int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(a));
+                if (loads == 7) hipLaunchKernelGGL((chase<7, true>), dim3(blocks), dim3(256), 0, 0, d, (uint32_t)(n - 1), steps, lanes, out);
+                else hipLaunchKernelGGL((chase<3, true>), dim3(blocks), dim3(256), 0, 0, d, (uint32_t)(n - 1), steps, lanes, out);
+                CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+            }
+            float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+            const double visits = (double)blocks * 4 * lanes * steps;
+            printf(",\n  {\"scatter\": true, \"table_mib\": %zu, \"waves_per_simd\": %d, \"loads_per_visit\": %d, \"lanes\": %d, \"steps\": %d, \"record_visits\": %.0f, \"ms\": %.3f, \"g_visits_per_s\": %.2f, \"gb_per_s_at_128B_per_visit\": %.0f}",
+                   n * 128 >> 20, waves, loads, lanes, steps, visits, ms, visits / ms * 1e-6, visits * 128.0 / ms * 1e-6);
         }
         CHECK(hipFree(d));
     }
