@@ -289,6 +289,11 @@ int64_t pt_debug_div_selftest(pt_ctx *ctx, int32_t millions, uint64_t seed);
  * child boxes not inside the parent's box, planes kept outside the tree}. */
 int32_t pt_debug_bvh_check(const pt_scene *scene, int32_t out[8]);
 
+/* Diagnostics only: how a context that holds several devices collects the tiles of a frame on devices[0]: 0 = one
+ * hipMemcpyPeerAsync per peer (the default), 1 = grouped ncclSend / ncclRecv through librccl.so (PTCORE_GATHER=rccl at
+ * pt_create; the library is dlopen'ed then and only then). */
+int32_t pt_debug_gather_mode(pt_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,7 @@ SYMBOLS = [
     ("pt_debug_scan_mismatches", C.c_int64, [_vp]),
     ("pt_debug_div_selftest", C.c_int64, [_vp, C.c_int32, C.c_uint64]),
     ("pt_debug_bvh_check", C.c_int32, [C.POINTER(PtScene), C.POINTER(C.c_int32)]),
+    ("pt_debug_gather_mode", C.c_int32, [_vp]),
 ]
 
 

@@ -11,6 +11,8 @@
 // There is no CPU rendering path in this library: without a HIP device every entry
 // point fails with PT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is loaded on request (PTCORE_GATHER=rccl), never linked
 
 #include <algorithm>
 #include <chrono>
@@ -213,6 +215,20 @@ struct pt_ctx {
     int split_rounds = 2;  // PTCORE_SPLIT_ROUNDS: trace + glass pass pairs per chunk before the all-in-one pass (bitmask scan only)
     bool primary_coop = true;  // PTCORE_PRIMARY=lane: BVH scenes without the wave-cooperative primary pass (the round-3 loop)
     bool tail_nested = true;  // PTCORE_TAIL=trip: the pass behind the split rounds in the round-1 form (exit search = the lane's next trip) instead of FORM_NESTED
+    // PTCORE_GATHER=rccl: the tiles of a frame reach devices[0] through RCCL (grouped ncclSend / ncclRecv over one communicator per
+    // device, ncclCommInitAll) instead of hipMemcpyPeerAsync.  librccl.so is dlopen'ed then and only then.
+    struct Rccl {
+        void *lib = nullptr;
+        std::vector<ncclComm_t> comms;
+        decltype(&ncclCommInitAll) CommInitAll = nullptr;
+        decltype(&ncclCommDestroy) CommDestroy = nullptr;
+        decltype(&ncclGroupStart) GroupStart = nullptr;
+        decltype(&ncclGroupEnd) GroupEnd = nullptr;
+        decltype(&ncclSend) Send = nullptr;
+        decltype(&ncclRecv) Recv = nullptr;
+        decltype(&ncclGetErrorString) GetErrorString = nullptr;
+        uint64_t gathers = 0;  // frames gathered through it
+    } rccl;
     uint32_t claim = 0;   // jobs per queue claim; 0 = by pass shape (dev_step), PTCORE_CLAIM forces one
     int max_blocks_per_cu = 8;
     int scan_mode = -1;  // -1 = choose by scene size; PTCORE_SCAN=uniform|broad|verify|bvh|verify_bvh forces one
@@ -1557,6 +1573,51 @@ void fill_stats_common(pt_ctx *ctx, pt_stats *st) {
 
 // ==================================================================== C ABI
 
+namespace {
+
+// Loads librccl.so and makes one communicator per device of the context (one process, ncclCommInitAll).  RCCL refuses a
+// device list that names one GPU twice -- the "virtual devices" of the tests -- and so does this.
+int32_t rccl_open(pt_ctx *ctx) {
+    pt_ctx::Rccl &R = ctx->rccl;
+    const char *path = std::getenv("PTCORE_RCCL_LIB");
+    // A process that already has an RCCL (PyTorch brings its own, soname librccl.so.1) must not get a second copy of it: ask for
+    // the loaded one first.
+    void *lib = path ? dlopen(path, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!lib && !path) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib && !path) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib && !path) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(PT_ERR_HIP, std::string("PTCORE_GATHER=rccl: cannot load librccl.so: ") + dlerror());
+#define PT_RCCL_SYM(field, name)                                                              \
+    R.field = reinterpret_cast<decltype(R.field)>(dlsym(lib, name));                          \
+    if (!R.field) return fail(PT_ERR_HIP, std::string("PTCORE_GATHER=rccl: librccl.so has no ") + name);
+    PT_RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    PT_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    PT_RCCL_SYM(GroupStart, "ncclGroupStart")
+    PT_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+    PT_RCCL_SYM(Send, "ncclSend")
+    PT_RCCL_SYM(Recv, "ncclRecv")
+    PT_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef PT_RCCL_SYM
+    std::vector<int> devs;
+    for (const Device &d : ctx->devs) devs.push_back(d.ordinal);
+    R.comms.assign(devs.size(), nullptr);
+    const ncclResult_t r = R.CommInitAll(R.comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) {
+        R.comms.clear();
+        return fail(PT_ERR_HIP, std::string("PTCORE_GATHER=rccl: ncclCommInitAll: ") + R.GetErrorString(r));
+    }
+    R.lib = lib;
+    return PT_OK;
+}
+
+#define RCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        const ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess) return fail(PT_ERR_HIP, std::string(#expr ": ") + ctx->rccl.GetErrorString(r_)); \
+    } while (0)
+
+}  // namespace
+
 extern "C" {
 
 int32_t pt_abi_version(void) { return PT_ABI_VERSION; }
@@ -1637,12 +1698,32 @@ int32_t pt_create(const int32_t *devices, int32_t ndev, pt_ctx **out) {
             if (e != hipSuccess) (void)hipGetLastError();  // already enabled or refused: the copy path copes
         }
     }
+    if (const char *e = std::getenv("PTCORE_GATHER")) {
+        if (!std::strcmp(e, "rccl")) {
+            if (int32_t rc = rccl_open(ctx)) {
+                pt_destroy(ctx);
+                return rc;
+            }
+        } else if (std::strcmp(e, "peer") != 0) {
+            pt_destroy(ctx);
+            return fail(PT_ERR_INVALID, "PTCORE_GATHER must be peer or rccl");
+        }
+    }
     *out = ctx;
     return PT_OK;
 }
 
+int32_t pt_debug_gather_mode(pt_ctx *ctx) { return ctx && ctx->rccl.lib ? 1 : 0; }
+
 void pt_destroy(pt_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->rccl.lib) {
+        for (size_t i = 0; i < ctx->rccl.comms.size(); i++)
+            if (ctx->rccl.comms[i] && hipSetDevice(ctx->devs[i].ordinal) == hipSuccess) (void)ctx->rccl.CommDestroy(ctx->rccl.comms[i]);
+        ctx->rccl.comms.clear();
+        // (the library stays mapped: RCCL keeps threads and device state of its own that a dlclose would pull away under them)
+        ctx->rccl.lib = nullptr;
+    }
     for (Device &d : ctx->devs) {
         if (hipSetDevice(d.ordinal) != hipSuccess) continue;
         if (d.own_stream) (void)hipStreamSynchronize(d.own_stream);
@@ -1914,7 +1995,7 @@ static int32_t read_frame(pt_ctx *ctx, uint8_t *rgba, int32_t stride, double *ac
         Device &d = ctx->devs[(size_t)i];
         if (d.nlocal == 0) continue;
         const size_t nt = (size_t)d.nlocal;
-        if (i == 0) {
+        if (i == 0 && !ctx->rccl.lib) {
             // device 0 resolves straight into the gather buffer
             if (int32_t rc = dev_finish(ctx, d, spp_done, ctx->g_tiles_rgba.p + before * 4096,
                                         accum ? ctx->g_tiles_accum.p + before * 3072 : nullptr,
@@ -1932,6 +2013,10 @@ static int32_t read_frame(pt_ctx *ctx, uint8_t *rgba, int32_t stride, double *ac
             if (int32_t rc = dev_finish(ctx, d, spp_done, d.tiles_rgba.p, accum ? d.tiles_accum.p : nullptr,
                                         want_stats ? d.tiles_seg.p : nullptr, want_stats ? d.tiles_draw.p : nullptr))
                 return rc;
+            if (ctx->rccl.lib) {  // the exchange itself follows the loop, all devices in one RCCL group
+                before += nt;
+                continue;
+            }
             // gather over xGMI: peer DMA into device 0's buffer, ordered on the source stream
             HIP_TRY(hipMemcpyPeerAsync(ctx->g_tiles_rgba.p + before * 4096, d0.ordinal, d.tiles_rgba.p, d.ordinal,
                                        nt * 4096, d.stream));
@@ -1946,6 +2031,34 @@ static int32_t read_frame(pt_ctx *ctx, uint8_t *rgba, int32_t stride, double *ac
             }
         }
         before += nt;
+    }
+    if (ctx->rccl.lib) {
+        // RCCL gather of the per-tile framebuffers: every device (devices[0] too: its own share travels the same way) sends its
+        // tiles to rank 0 on its stream, rank 0 posts the matching receives on its stream -- one group, so that the sends and
+        // receives of this one process pair up without deadlock (ncclGather is this same pattern; the counts differ per rank here)
+        const pt_ctx::Rccl &R = ctx->rccl;
+        RCCL_TRY(R.GroupStart());
+        size_t off = 0;
+        for (int32_t i = 0; i < ndev; i++) {
+            Device &d = ctx->devs[(size_t)i];
+            if (d.nlocal == 0) continue;
+            const size_t nt = (size_t)d.nlocal;
+            RCCL_TRY(R.Send(d.tiles_rgba.p, nt * 4096, ncclUint8, 0, R.comms[(size_t)i], d.stream));
+            RCCL_TRY(R.Recv(ctx->g_tiles_rgba.p + off * 4096, nt * 4096, ncclUint8, i, R.comms[0], d0.stream));
+            if (accum) {
+                RCCL_TRY(R.Send(d.tiles_accum.p, nt * 3072, ncclDouble, 0, R.comms[(size_t)i], d.stream));
+                RCCL_TRY(R.Recv(ctx->g_tiles_accum.p + off * 3072, nt * 3072, ncclDouble, i, R.comms[0], d0.stream));
+            }
+            if (want_stats) {
+                RCCL_TRY(R.Send(d.tiles_seg.p, nt * 1024, ncclUint32, 0, R.comms[(size_t)i], d.stream));
+                RCCL_TRY(R.Recv(ctx->g_tiles_seg.p + off * 1024, nt * 1024, ncclUint32, i, R.comms[0], d0.stream));
+                RCCL_TRY(R.Send(d.tiles_draw.p, nt * 1024, ncclUint32, 0, R.comms[(size_t)i], d.stream));
+                RCCL_TRY(R.Recv(ctx->g_tiles_draw.p + off * 1024, nt * 1024, ncclUint32, i, R.comms[0], d0.stream));
+            }
+            off += nt;
+        }
+        RCCL_TRY(R.GroupEnd());
+        ctx->rccl.gathers++;
     }
     for (int32_t i = 1; i < ndev; i++) {
         HIP_TRY(hipSetDevice(ctx->devs[(size_t)i].ordinal));

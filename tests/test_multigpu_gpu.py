@@ -39,6 +39,26 @@ def _one_device_frame(gpu_ctx):
 
 
 @needs_two
+def test_in_process_devices_with_the_rccl_gather(gpu_ctx, monkeypatch):
+    """The same frame with the tiles collected through RCCL (PTCORE_GATHER=rccl: grouped ncclSend / ncclRecv over xGMI)."""
+    from path_trace_golang_amd import capi, hip
+
+    sc, img1, acc1, st1 = _one_device_frame(gpu_ctx)
+    monkeypatch.setenv("PTCORE_GATHER", "rccl")
+    n = _ndev()
+    for devs in ([0, 1], list(range(n)), [1, 0]):
+        with capi.Context(devices=devs) as ctx:
+            assert capi.load().pt_debug_gather_mode(ctx.handle) == 1
+            for _ in range(2):  # a communicator serves frame after frame
+                img = np.zeros((H, W, 4), np.uint8)
+                acc = np.zeros((H, W, 3))
+                st = hip.render(sc, hip.RenderConfig(W, H, SPP, DEPTH, SEED), img, None, acc, ctx=ctx)
+                assert st["num_devices"] == len(devs) and st["segments"] == st1["segments"]
+                assert np.array_equal(img, img1), "frame differs on devices %s" % devs
+                assert np.array_equal(acc, acc1)
+
+
+@needs_two
 def test_in_process_devices_give_the_one_device_frame(gpu_ctx):
     from path_trace_golang_amd import capi, hip
 
