@@ -66,6 +66,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the p
                           // push_keep_bit it needs 87 registers; held to 80 it spills two and is 2.2 % faster at six waves than at five
                           // (profiles/r03_occ_c4.txt, second block; before that change six waves lost 2.3 %)
 #endif
+#ifndef PT_BROAD_UNROLL
+#define PT_BROAD_UNROLL 4  // records per turn of the broad-phase loops of the single-group scan: all their scalar loads are issued before the first
+                           // record is used.  Same box, C4: 530.6 / 526.8 / 524.4 ms per frame for 1 / 2 / 4 (profiles/r04_broad_unroll_ab.txt)
+#endif
+#ifndef PT_NESTED_WAVES
+#define PT_NESTED_WAVES PT_FLAT_WAVES  // ... and the pass behind the split rounds (FORM_NESTED)
+#endif
 #define PT_HOLE 0xffffffffu     // job id of a reserved but unused queue slot
 // The host sizes every path-state queue as (entries a pass can append) + (waves of the widest writer grid) x (the larger
 // window): queue_slack() in ptcore.hip.  What that arithmetic relies on:
@@ -598,8 +605,11 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     const float tmin_d = tminf * (fa * inv_len);
     // candidate masks: the k-th of n sphere records in bit n - 1 - k of `cs`, likewise the boxes in `cb` (<= 32 of each; push_keep_bit)
     uint32_t cs = 0, cb = 0;
-    for (int k = 0; k < BL.n_bsph; k++) {
-        const auto &s = BL.bs[k];
+    // (two records per turn, both fetched before the first is used: the scalar loads of the second hide behind the first one's
+    // 18 vector instructions; the compiler does not unroll across the asm of push_keep_bit by itself)
+    // (Round 4 also tried |q|^2 = |oc|^2 - sd^2 with an explicit error term on the culling side of the compare -- 16 instead of 18 vector
+    // instructions per record: trace passes 441.0 -> 440.1 ms per C4 frame, i.e. nothing; profiles/r04_broad_unroll_ab.txt.  Not kept.)
+    auto sphere_record = [&](const auto &s) {
         const float ocx = fox - s.cx, ocy = foy - s.cy, ocz = foz - s.cz;
         const float sd = __builtin_fmaf(ocx, ux, __builtin_fmaf(ocy, uy, ocz * uz));  // minus the distance of closest approach
         const float qx = __builtin_fmaf(-sd, ux, ocx), qy = __builtin_fmaf(-sd, uy, ocy), qz = __builtin_fmaf(-sd, uz, ocz);
@@ -608,16 +618,69 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         const float w = __builtin_fmaxf(tmin_d + sd, 0.0f);  // > 0: closest approach lies before tMin
         // outside (rem < 0) or wholly behind (w^2 > rem) in one compare, as w^2 >= 0; NaN keeps the sphere
         push_keep_bit(cs, rem, w * w);
+    };
+    {
+        int k = 0;
+        struct Rec { float cx, cy, cz, rm2; };
+#if PT_BROAD_UNROLL >= 4
+        for (; k + 3 < BL.n_bsph; k += 4) {
+            const auto &a0 = BL.bs[k];
+            const auto &a1 = BL.bs[k + 1];
+            const auto &a2 = BL.bs[k + 2];
+            const auto &a3 = BL.bs[k + 3];
+            const Rec r0{a0.cx, a0.cy, a0.cz, a0.rm2}, r1{a1.cx, a1.cy, a1.cz, a1.rm2}, r2{a2.cx, a2.cy, a2.cz, a2.rm2}, r3{a3.cx, a3.cy, a3.cz, a3.rm2};
+            sphere_record(r0);
+            sphere_record(r1);
+            sphere_record(r2);
+            sphere_record(r3);
+        }
+#endif
+        for (; k + 1 < BL.n_bsph; k += 2) {
+            const auto &a0 = BL.bs[k];
+            const auto &a1 = BL.bs[k + 1];
+            const Rec r0{a0.cx, a0.cy, a0.cz, a0.rm2}, r1{a1.cx, a1.cy, a1.cz, a1.rm2};
+            sphere_record(r0);
+            sphere_record(r1);
+        }
+        if (k < BL.n_bsph) sphere_record(BL.bs[k]);
     }
     const float ivxf = __builtin_amdgcn_rcpf(fdx), ivyf = __builtin_amdgcn_rcpf(fdy), ivzf = __builtin_amdgcn_rcpf(fdz);
     const float aivxf = __builtin_fabsf(ivxf), aivyf = __builtin_fabsf(ivyf), aivzf = __builtin_fabsf(ivzf);
     // -o/d: the extra rounding (~2^-24 |o| in distance) is far inside the margin, and inf - inf = NaN for a zero
     // direction component leaves that slab unconstrained
     const float noxf = -fox * ivxf, noyf = -foy * ivyf, nozf = -foz * ivzf;
-    for (int k = 0; k < BL.n_bbox; k++) {
-        const auto &bx = BL.bb[k];
+    auto box_record = [&](const auto &bx) {
         PT_BOX_SLABS(bx, t0, t1)
         push_keep_bit(cb, t1, t0);
+    };
+    {
+        int k = 0;
+        struct Rec { float c[3], h[3]; };
+#if PT_BROAD_UNROLL >= 4
+        for (; k + 3 < BL.n_bbox; k += 4) {
+            const auto &a0 = BL.bb[k];
+            const auto &a1 = BL.bb[k + 1];
+            const auto &a2 = BL.bb[k + 2];
+            const auto &a3 = BL.bb[k + 3];
+            const Rec b0{{a0.c[0], a0.c[1], a0.c[2]}, {a0.h[0], a0.h[1], a0.h[2]}};
+            const Rec b1{{a1.c[0], a1.c[1], a1.c[2]}, {a1.h[0], a1.h[1], a1.h[2]}};
+            const Rec b2{{a2.c[0], a2.c[1], a2.c[2]}, {a2.h[0], a2.h[1], a2.h[2]}};
+            const Rec b3{{a3.c[0], a3.c[1], a3.c[2]}, {a3.h[0], a3.h[1], a3.h[2]}};
+            box_record(b0);
+            box_record(b1);
+            box_record(b2);
+            box_record(b3);
+        }
+#endif
+        for (; k + 1 < BL.n_bbox; k += 2) {
+            const auto &a0 = BL.bb[k];
+            const auto &a1 = BL.bb[k + 1];
+            const Rec b0{{a0.c[0], a0.c[1], a0.c[2]}, {a0.h[0], a0.h[1], a0.h[2]}};
+            const Rec b1{{a1.c[0], a1.c[1], a1.c[2]}, {a1.h[0], a1.h[1], a1.h[2]}};
+            box_record(b0);
+            box_record(b1);
+        }
+        if (k < BL.n_bbox) box_record(BL.bb[k]);
     }
     if (!trust) { cs = BL.sph_all; cb = BL.box_all; }
     if (outside_all) { cs = 0; cb = 0; }
@@ -1558,6 +1621,7 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                                        : (SCAN == SCAN_BVH || SCAN == SCAN_VERIFY_BVH) ? PT_BVH_WAVES
                                        : ((SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE) && FORM != FORM_SPLIT && PT_FLAT_WAVES > 4) ? 4
                                        : (SCAN == SCAN_BROAD && FORM == FORM_SPLIT && !STATS)                                                  ? PT_SPLIT_WAVES
+                                       : (SCAN == SCAN_BROAD && FORM == FORM_NESTED && !STATS)                                                 ? PT_NESTED_WAVES
                                                                                                                                : PT_FLAT_WAVES) void trace_kernel(const TraceArgs A) {
     constexpr bool SPLIT = FORM == FORM_SPLIT;
     constexpr bool NEST = FORM == FORM_NESTED;
@@ -2149,24 +2213,29 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
     const size_t qg = B.glass.cap, qc = B.cont.cap;
     uint32_t q_cur = 0, q_end = 0;  // this wave's window of continuation slots (see trace_kernel: one atomic per window)
 
-    for (uint32_t i0 = blockIdx.x * PT_BLOCK + (threadIdx.x & ~(PT_WAVE - 1u)); i0 < n; i0 += gridDim.x * PT_BLOCK) {
+    // (the wave's first entry is wave-uniform: said so, every plane of the entry is then read at a scalar base + the lane's offset
+    // instead of a 64-bit vector address per plane -- 14 planes in, 12 out per entry; 8 spilled SGPRs instead of 19.  No change in
+    // time: profiles/r04_glass_ab.txt)
+    for (uint32_t i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * PT_BLOCK + (threadIdx.x & ~(PT_WAVE - 1u))); i0 < n; i0 += gridDim.x * PT_BLOCK) {
         const uint32_t i = i0 + lane;
-        const bool live = i < n && KB->glass.job[i] != PT_HOLE;
+        const auto gq = &KB->glass;
+        const bool live = i < n && (gq->job + i0)[lane] != PT_HOLE;
         bool go_on = false;
         double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, Tx = 0, Ty = 0, Tz = 0;
         uint64_t rs = 0;
         uint32_t job = 0, j_seg = 0, j_draw = 0;
         int depth = 0;
         if (live) {
-            ox = KB->glass.d[i]; oy = KB->glass.d[qg + i]; oz = KB->glass.d[2 * qg + i];
-            dx = KB->glass.d[3 * qg + i]; dy = KB->glass.d[4 * qg + i]; dz = KB->glass.d[5 * qg + i];
-            Tx = KB->glass.d[6 * qg + i]; Ty = KB->glass.d[7 * qg + i]; Tz = KB->glass.d[8 * qg + i];
-            const double tmax = KB->glass.d[9 * qg + i];
-            rs = KB->glass.rs[i];
-            job = KB->glass.job[i];
-            depth = KB->glass.depth[i];
-            const int best = KB->glass.best[i];
-            if (STATS) { j_seg = KB->glass.jseg[i]; j_draw = KB->glass.jdraw[i]; }
+            const double *q0 = gq->d + i0;
+            ox = q0[lane]; oy = (q0 + qg)[lane]; oz = (q0 + 2 * qg)[lane];
+            dx = (q0 + 3 * qg)[lane]; dy = (q0 + 4 * qg)[lane]; dz = (q0 + 5 * qg)[lane];
+            Tx = (q0 + 6 * qg)[lane]; Ty = (q0 + 7 * qg)[lane]; Tz = (q0 + 8 * qg)[lane];
+            const double tmax = (q0 + 9 * qg)[lane];
+            rs = (gq->rs + i0)[lane];
+            job = (gq->job + i0)[lane];
+            depth = (gq->depth + i0)[lane];
+            const int best = (gq->best + i0)[lane];
+            if (STATS) { j_seg = (gq->jseg + i0)[lane]; j_draw = (gq->jdraw + i0)[lane]; }
 
             // hit record of the winner
             const DevObj &o = lds_obj[best];
@@ -2252,6 +2321,7 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
             }
             const uint32_t rank = lane_rank(pm);
             const uint32_t slot = rank < room ? q_cur + rank : nbase + (rank - room);
+            const uint32_t q_cur0 = q_cur;
             if (np > room) {
                 q_cur = nbase + (np - room);
                 q_end = nbase + PT_CONT_BLOCK;
@@ -2261,19 +2331,27 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
             if (go_on && slot >= B.cont.cap) {
                 atomicAdd(KB->counters + 19, 1ull);  // cannot happen; never write outside the queue
             } else if (go_on) {
-                KB->cont.d[slot] = ox;
-                KB->cont.d[qc + slot] = oy;
-                KB->cont.d[2 * qc + slot] = oz;
-                KB->cont.d[3 * qc + slot] = dx;
-                KB->cont.d[4 * qc + slot] = dy;
-                KB->cont.d[5 * qc + slot] = dz;
-                KB->cont.d[6 * qc + slot] = Tx;
-                KB->cont.d[7 * qc + slot] = Ty;
-                KB->cont.d[8 * qc + slot] = Tz;
-                KB->cont.rs[slot] = rs;
-                KB->cont.job[slot] = job;
-                KB->cont.depth[slot] = depth;
-                if (STATS) { KB->cont.jseg[slot] = j_seg; KB->cont.jdraw[slot] = j_draw; }
+                const auto cq = &KB->cont;
+                // entry `idx` past slot `base` of every plane (as trace_kernel's push: nearly every push fits the wave's window, and
+                // its addresses are then the window cursor, a scalar, + the lane's rank)
+                auto store_entry = [&](size_t base, uint32_t idx) {
+                    double *q0 = cq->d + base;
+                    q0[idx] = ox;
+                    (q0 + qc)[idx] = oy;
+                    (q0 + 2 * qc)[idx] = oz;
+                    (q0 + 3 * qc)[idx] = dx;
+                    (q0 + 4 * qc)[idx] = dy;
+                    (q0 + 5 * qc)[idx] = dz;
+                    (q0 + 6 * qc)[idx] = Tx;
+                    (q0 + 7 * qc)[idx] = Ty;
+                    (q0 + 8 * qc)[idx] = Tz;
+                    (cq->rs + base)[idx] = rs;
+                    (cq->job + base)[idx] = job;
+                    (cq->depth + base)[idx] = depth;
+                    if (STATS) { (cq->jseg + base)[idx] = j_seg; (cq->jdraw + base)[idx] = j_draw; }
+                };
+                if (np <= room) store_entry(q_cur0, rank & 63u);
+                else store_entry(0, slot);
                 c_cont++;
             }
         }
