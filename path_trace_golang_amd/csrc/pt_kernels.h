@@ -788,8 +788,8 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
         const int cnt = BL.n_bsph - base < 32 ? BL.n_bsph - base : 32;
         PH_BEGIN(SEC_BROAD)
         uint32_t cs = 0, diel = 0;
-        for (int k = 0; k < cnt; k++) {
-            const auto &s = BL.bs[base + k];
+        struct SRec { float cx, cy, cz, rm2; int32_t diel; };
+        auto sphere_record = [&](const SRec &s) {
             const float ocx = fox - s.cx, ocy = foy - s.cy, ocz = foz - s.cz;
             const float b = __builtin_fmaf(ocx, fdx, __builtin_fmaf(ocy, fdy, ocz * fdz));
             const float tca = -b * inv_a;
@@ -799,6 +799,17 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
             const float w = __builtin_fmaxf(tminf - tca, 0.0f);
             push_keep_bit(cs, rem, w * w * fa);
             diel = (diel << 1) | (s.diel ? 1u : 0u);  // wave-uniform: scalar unit (same bit order as cs)
+        };
+        {   // four records per turn, their scalar loads issued first (see scan_broad_narrow)
+            int k = 0;
+            for (; k + 3 < cnt; k += 4) {
+                SRec r[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const auto &a = BL.bs[base + k + q]; r[q] = SRec{a.cx, a.cy, a.cz, a.rm2, a.diel}; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) sphere_record(r[q]);
+            }
+            for (; k < cnt; k++) { const auto &a = BL.bs[base + k]; sphere_record(SRec{a.cx, a.cy, a.cz, a.rm2, a.diel}); }
         }
         if (!trust) cs = cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
         if (outside_all) cs = 0;
@@ -828,11 +839,22 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
             const int cnt = BL.n_bbox - base < 32 ? BL.n_bbox - base : 32;
             PH_BEGIN(SEC_BROAD)
             uint32_t cb = 0, diel = 0;
-            for (int k = 0; k < cnt; k++) {
-                const auto &bx = BL.bb[base + k];
+            struct BRec { float c[3], h[3]; int32_t diel; };
+            auto box_record = [&](const BRec &bx) {
                 PT_BOX_SLABS(bx, t0, t1)
                 push_keep_bit(cb, t1, t0);
                 diel = (diel << 1) | (bx.diel ? 1u : 0u);
+            };
+            {
+                int k = 0;
+                for (; k + 3 < cnt; k += 4) {
+                    BRec r[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const auto &a = BL.bb[base + k + q]; r[q] = BRec{{a.c[0], a.c[1], a.c[2]}, {a.h[0], a.h[1], a.h[2]}, a.diel}; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) box_record(r[q]);
+                }
+                for (; k < cnt; k++) { const auto &a = BL.bb[base + k]; box_record(BRec{{a.c[0], a.c[1], a.c[2]}, {a.h[0], a.h[1], a.h[2]}, a.diel}); }
             }
             if (!trust) cb = cnt == 32 ? 0xffffffffu : ((1u << cnt) - 1u);
             if (outside_all) cb = 0;
