@@ -6,8 +6,8 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one whole frame of BASELINE config 4, the configuration the metric is
-quoted on: scenes/gpu_showcase.json at 1920x1080, 1024 spp, max depth 8 (synthetic in
-the sense that it is the scene file itself; there are no weights or datasets).  The
+quoted on: scenes/gpu_showcase.json at 1920x1080, 1024 spp, max depth 8 (the reference's
+own scene file; there are no weights or datasets, and nothing synthetic).  The
 frame is split over interleaved 32x32 tiles, one process per GPU; each rank renders
 its tiles through the C ABI (pt_render_tiles_device), the per-tile framebuffers are
 gathered on rank 0 over RCCL (torch.distributed "nccl" gather) and untiled there.  No
@@ -292,7 +292,7 @@ def main() -> int:
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "scene file (scenes/%s.json, byte-identical to the reference's; nothing here is synthetic)" % args.scene,
             "config": {"workload": "scenes/%s.json %dx%d, %d spp, max depth %d, seed %d (%s)"
                                    % (args.scene, W, H, args.spp, args.depth, args.seed,
                                       ("BASELINE config %s" % config_id[1] + ("" if config_full else " at %d of its %d spp" % (args.spp, CONFIGS[config_id][3])))
