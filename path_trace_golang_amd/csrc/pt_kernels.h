@@ -2143,6 +2143,13 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
 #undef PT_DRAW
 #undef SEC_BEGIN
 #undef SEC_END
+    if (!PROF) {
+        // PTCORE_DEBUG_TIMELINE (diagnostics): when every wave of the launch retired, in ticks of the 100 MHz counter (the host prints
+        // how far apart the waves of a launch finish; B.prof holds one word per wave of the widest launch then).  The pointer is re-read
+        // from the kernarg segment here: kept in scalar registers through the loop it cost the headline kernel three more spilled SGPRs.
+        unsigned long long *tl = pt_launder(ka)->B.prof;
+        if (tl != nullptr && lane == 0) tl[(blockIdx.x * PT_BLOCK + threadIdx.x) >> 6] = __builtin_amdgcn_s_memrealtime();
+    }
     if (PROF) {
 #pragma unroll
         for (int i = 0; i < SEC_COUNT; i++) {

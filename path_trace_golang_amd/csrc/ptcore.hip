@@ -1029,6 +1029,11 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
     B.queue = d.queue.p;
     B.counters = d.counters.p;
     B.prof = ctx->profile_sections ? d.prof.p : nullptr;
+    const bool timeline = !ctx->profile_sections && std::getenv("PTCORE_DEBUG_TIMELINE") != nullptr;  // diagnostics: when each wave of a trace launch retires
+    if (timeline) {
+        HIP_TRY(d.prof.reserve(65536));
+        B.prof = d.prof.p;
+    }
 
     const int rounds = fr.split_rounds;
     if (int32_t rc = dev_events(d, d.ev_trace, d.n_trace + (size_t)rounds + 2)) return rc;
@@ -1100,6 +1105,19 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
                                dim3(grid), dim3(PT_BLOCK), lds, d.stream, A);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(e.b, d.stream));
+            if (timeline) {
+                HIP_TRY(hipStreamSynchronize(d.stream));
+                const uint32_t nw = std::min(grid * 4u, 65536u);
+                std::vector<unsigned long long> t(nw);
+                HIP_TRY(hipMemcpy(t.data(), d.prof.p, nw * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                std::sort(t.begin(), t.end());
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+                auto back = [&](double q) { return (double)(t[nw - 1] - t[(size_t)(q * (nw - 1))]) * 1e-5; };  // ms before the last wave
+                std::fprintf(stderr, "ptcore timeline: %s form %d  %.3f ms, %u waves; before the last wave retired: first %.3f ms, 1 %% %.3f, 10 %% %.3f, 25 %% %.3f, 50 %% %.3f, 75 %% %.3f, 90 %% %.3f, 99 %% %.3f; mean %.3f ms\n",
+                             split ? "trace<split>" : "trace<tail>", split ? 1 : fr.tail_form, ms, nw, back(0.0), back(0.01), back(0.10), back(0.25), back(0.50), back(0.75), back(0.90), back(0.99),
+                             [&] { double a = 0; for (auto v : t) a += (double)(t[nw - 1] - v); return a / nw * 1e-5; }());
+            }
             if (pass_log) {  // PTCORE_DEBUG_PASS_LOG=1 (diagnostics): what every trace pass did; serialises the stream
                 HIP_TRY(hipStreamSynchronize(d.stream));
                 unsigned long long c[24];
