@@ -66,3 +66,44 @@ def test_a_budget_beyond_the_device_halves_the_pass_once(monkeypatch, capfd):
         assert st["segments"] == st_ref["segments"]
         assert np.array_equal(img, img_ref)
         assert np.array_equal(acc, acc_ref)
+
+
+def test_a_context_grows_its_job_buffers_on_the_second_frame_of_one_shape(monkeypatch):
+    """pt_render with library defaults (what a Go host calls once per frame, gpu.go:2534-2546): the first frame of a shape is cut
+    into the passes 48 GiB of job buffers allow, the second frame of the SAME shape takes the 160 GiB size by itself when the device
+    has it free -- fewer passes, the same pixels; another shape starts small again; PTCORE_AUTO_GROW=0 or an explicit
+    PTCORE_L_BUDGET_MB keep the size fixed."""
+    from conftest import scene_path
+    from path_trace_golang_amd import capi, hip, scene
+
+    sc = scene.load(scene_path("test_scene"))
+    w, h, spp, depth = 1920, 1080, 320, 1  # 2.07 M pixel slots x 320 spp x 310 B = 206 GB of job buffers for one pass
+    monkeypatch.delenv("PTCORE_L_BUDGET_MB", raising=False)
+    monkeypatch.delenv("PTCORE_AUTO_GROW", raising=False)
+    frames = []
+    with capi.Context(ndev=1) as ctx:
+        for _ in range(3):
+            img = np.zeros((h, w, 4), np.uint8)
+            st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, 4), img, ctx=ctx)
+            frames.append((img, st["spp_chunk"], st["segments"]))
+        small = np.zeros((90, 160, 4), np.uint8)
+        hip.render(sc, hip.RenderConfig(160, 90, 8, depth, 4), small, ctx=ctx)  # another shape in between
+        img = np.zeros((h, w, 4), np.uint8)
+        st = hip.render(sc, hip.RenderConfig(w, h, spp, depth, 4), img, ctx=ctx)
+        frames.append((img, st["spp_chunk"], st["segments"]))
+    assert frames[0][1] < spp  # the first frame needed several passes
+    for f in frames[1:]:
+        assert np.array_equal(f[0], frames[0][0]) and f[2] == frames[0][2]  # pixels do not depend on the chunking
+    if frames[1][1] == frames[0][1]:
+        pytest.skip("the device does not have 160 GiB + a tenth free right now (other contexts of this session hold them): no growth to look at")
+    assert frames[1][1] > frames[0][1] and frames[2][1] == frames[1][1]  # the second and third took the grown size (this box has the room)
+    assert frames[3][1] == frames[0][1]  # first frame of the shape again (the small one came in between): the small size
+    for f in frames[1:]:
+        assert np.array_equal(f[0], frames[0][0]) and f[2] == frames[0][2]  # pixels do not depend on the chunking
+    monkeypatch.setenv("PTCORE_AUTO_GROW", "0")
+    with capi.Context(ndev=1) as ctx:
+        chunks = []
+        for _ in range(2):
+            img = np.zeros((h, w, 4), np.uint8)
+            chunks.append(hip.render(sc, hip.RenderConfig(w, h, spp, depth, 4), img, ctx=ctx)["spp_chunk"])
+        assert chunks[0] == chunks[1] == frames[0][1] and np.array_equal(img, frames[0][0])

@@ -47,3 +47,23 @@ def test_queue_overflow_fails_the_frame_and_nothing_else(monkeypatch, oracle, gp
     assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"])
     assert np.array_equal(img, o["rgba"])
     assert np.all(np.abs(acc - o["accum"]) <= 4 * depth * 2.0 ** -52 * np.maximum(np.abs(o["accum"]), 1e-300))
+
+
+def test_queue_overflow_in_the_bvh_primary_pass(monkeypatch, oracle):
+    """BVH scenes: primary_bvh_kernel hands every path that goes on to the per-lane loop through the continuation queue (DESIGN 3.4a);
+    an undersized queue must fail the frame the same way."""
+    from path_trace_golang_amd import capi, synth
+
+    sc = synth.make_scene(300, 6)
+    w, h, spp, depth, seed = 160, 90, 4, 6, 3
+    monkeypatch.delenv("PTCORE_PIPELINE", raising=False)
+    with capi.Context(ndev=1) as ctx:
+        monkeypatch.setenv("PTCORE_DEBUG_QUEUE_CAP", "2000")  # the primary pass hands on ~50 000 paths
+        with pytest.raises(capi.PtError) as ei:
+            _frame(ctx, sc, w, h, spp, depth, seed)
+        assert ei.value.code == capi.PT_ERR_STATE and "queue overflowed" in str(ei.value)
+        monkeypatch.delenv("PTCORE_DEBUG_QUEUE_CAP")
+        st, img, acc, nseg, ndraw = _frame(ctx, sc, w, h, spp, depth, seed)
+    o = oracle.render(oracle.Scene(sc.encode()), w, h, spp, depth, seed=seed)
+    assert st["segments"] == o["stats"]["segments"] and st["draws"] == o["stats"]["draws"]
+    assert np.array_equal(nseg, o["nseg"]) and np.array_equal(ndraw, o["ndraw"]) and np.array_equal(img, o["rgba"])
