@@ -484,8 +484,9 @@ __device__ __attribute__((noinline)) LinearHit scan_linear_wave(int nobj, const 
 
 // The record lists one bitmask scan runs over: every finite object (closest-hit scans, and exit searches of the
 // all-in-one kernel, which mask the dielectric ones) or the dielectric objects only (exit searches of glass_kernel).
-template <typename SphPtr, typename BoxPtr>
+template <typename SphPtr, typename BoxPtr, bool RECORD_ORDER = false>
 struct BroadLists {
+    static constexpr bool RO = RECORD_ORDER;
     SphPtr bs;             // sphere records (scalar loads)
     BoxPtr bb;             // box records
     int n_bsph, n_bbox;    // <= 32 each
@@ -493,6 +494,11 @@ struct BroadLists {
     uint32_t sph_diel, box_diel;  // records whose object is dielectric
     const int *kidx_s;     // LDS: record -> object index
     const int *kidx_b;
+    // LDS, single-group scans of trace_kernel (round 4): the objects again IN RECORD ORDER (slot of push_keep_bit), file index in bits 16-31
+    // of `kind`: a narrow-phase round reads its object at ctz(mask) * 80 instead of going through kidx first (one dependent LDS read and
+    // three instructions fewer per round); used when RECORD_ORDER
+    const DevObj *rs = nullptr;
+    const DevObj *rb = nullptr;
 };
 
 // Slab parameters of one inflated box from its centre c and half extent h (both rounded so that [c-h, c+h] holds the
@@ -552,8 +558,8 @@ __host__ __device__ __forceinline__ int pt_record_slot(int i, int n) {
 
 // Broad phase in FP32 over inflated bounds + exact FP64 narrow phase over the survivors.
 // MODE: 0 closest hit, 1 exit search, -1 decided per lane by `mode_rt`.
-template <bool PROF, bool DBG, int MODE, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
-__device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_obj, const BroadLists<SphPtr, BoxPtr> &BL, IdxPtr g_pl,
+template <bool PROF, bool DBG, int MODE, typename ObjPtr, typename BLT, typename IdxPtr>
+__device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_obj, const BLT &BL, IdxPtr g_pl,
                                                   const DevObj *s_obj, const RayD &r, const Clip &clip,
                                                   int mode_rt, int &best, double &tmax, const ProfHooks &ph) {
     const int mode = MODE < 0 ? mode_rt : MODE;
@@ -699,9 +705,10 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     while (__ballot(ms != 0) != 0) {
         if (ms != 0) {
             PH_BEGIN(SEC_NSPH)
-            const int i = BL.kidx_s[__builtin_ctz(ms)];  // record -> object index; records are in file order
+            const int slot_ = __builtin_ctz(ms);
             ms &= ms - 1;
-            const DevObj &o = s_obj[i];
+            const DevObj &o = BLT::RO ? BL.rs[slot_] : s_obj[BL.kidx_s[BLT::RO ? 0 : slot_]];
+            const int i = BLT::RO ? (int)((uint32_t)o.kind >> 16) : BL.kidx_s[BLT::RO ? 0 : slot_];  // record -> object index
             double t = 0;
             bool acc = sphere_exact_shared(o.a[0], o.a[1], o.a[2], o.radius_sq, r, a, ya, tmin, tmax, t) &&
                        wins(mode, false, i, t, best, best_is_box, tmax);
@@ -719,9 +726,10 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
         while (__ballot(mb != 0) != 0) {
             if (mb != 0) {
                 PH_BEGIN(SEC_NBOX)
-                const int i = BL.kidx_b[__builtin_ctz(mb)];
+                const int slot_ = __builtin_ctz(mb);
                 mb &= mb - 1;
-                const DevObj &o = s_obj[i];
+                const DevObj &o = BLT::RO ? BL.rb[slot_] : s_obj[BL.kidx_b[BLT::RO ? 0 : slot_]];
+                const int i = BLT::RO ? (int)((uint32_t)o.kind >> 16) : BL.kidx_b[BLT::RO ? 0 : slot_];
                 double t = 0;
                 // the range is left open at the top here: `wins` compares t with tmax (strictly for a box)
                 bool acc = box_exact<true>(o.a[0], o.a[1], o.a[2], o.b[0], o.b[1], o.b[2], r, ivx, ivy, ivz, tmin, ptm::max_float64(), t) &&
@@ -740,8 +748,8 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
 // candidate mask at a time, so no more registers than the single-group version), the dielectric mask of a
 // group is collected from the records on the scalar unit.  Between ~33 and ~200 objects this linear scan at
 // full lanes beats the hierarchy, whose walks diverge.
-template <bool PROF, bool DBG, int MODE, typename ObjPtr, typename SphPtr, typename BoxPtr, typename IdxPtr>
-__device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr g_obj, const BroadLists<SphPtr, BoxPtr> &BL, IdxPtr g_pl,
+template <bool PROF, bool DBG, int MODE, typename ObjPtr, typename BLT, typename IdxPtr>
+__device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr g_obj, const BLT &BL, IdxPtr g_pl,
                                                        const DevObj *s_obj, const RayD &r, const Clip &clip,
                                                        int mode_rt, int &best, double &tmax, const ProfHooks &ph) {
     const int mode = MODE < 0 ? mode_rt : MODE;
@@ -1676,6 +1684,10 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
     }
     // object index of every broad-phase record (spheres, then boxes), for the per-lane narrow phase
     int *lds_kidx = reinterpret_cast<int *>(smem + (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat));
+    // single-group scans: the records' objects once more, in record order (behind the index tables, 16-byte aligned; ptcore.hip sizes the LDS for it)
+    constexpr bool RO = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY);
+    DevObj *lds_rec = reinterpret_cast<DevObj *>(smem + (((size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
+                                                            (size_t)(F.n_bsph + F.n_bbox + F.n_dsph + F.n_dbox) * sizeof(int) + 15) & ~(size_t)15));
     if (!BIG) {
         const uint64_t *g0 = reinterpret_cast<const uint64_t *>(B.objs);
         uint64_t *l0 = reinterpret_cast<uint64_t *>(lds_obj);
@@ -1694,6 +1706,34 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 for (int i = threadIdx.x; i < F.n_dbox; i += PT_BLOCK) kd[F.n_dsph + pt_record_slot(i, F.n_dbox)] = B.bbox_diel[i].index;
             }
         }
+        if (RO) {  // the objects of the records again, in record order, file index in bits 16-31 of `kind` (BroadLists::rs / rb)
+            uint64_t *lr = reinterpret_cast<uint64_t *>(lds_rec);
+            const int nr = F.n_bsph + F.n_bbox, W8 = (int)(sizeof(DevObj) / 8);
+            for (int q = threadIdx.x; q < nr * W8; q += PT_BLOCK) {
+                const int rcd = q / W8, wd = q - rcd * W8;
+                const bool sph = rcd < F.n_bsph;
+                const int k = sph ? rcd : rcd - F.n_bsph;
+                const int oi = sph ? B.bsph[k].index : B.bbox[k].index;
+                const int slot = sph ? pt_record_slot(k, F.n_bsph) : F.n_bsph + pt_record_slot(k, F.n_bbox);
+                uint64_t v = g0[(size_t)oi * W8 + wd];
+                if (wd == W8 - 1) v = (v & ~0xffff0000ull) | ((uint64_t)(uint32_t)oi << 16);  // last word: kind (low half), mat (high half)
+                lr[(size_t)slot * W8 + wd] = v;
+            }
+            if (NEST) {  // ... and those of the dielectric-only records of the nested exit search, behind them
+                uint64_t *ld = reinterpret_cast<uint64_t *>(lds_rec + nr);
+                const int nd = F.n_dsph + F.n_dbox;
+                for (int q = threadIdx.x; q < nd * W8; q += PT_BLOCK) {
+                    const int rcd = q / W8, wd = q - rcd * W8;
+                    const bool sph = rcd < F.n_dsph;
+                    const int k = sph ? rcd : rcd - F.n_dsph;
+                    const int oi = sph ? B.bsph_diel[k].index : B.bbox_diel[k].index;
+                    const int slot = sph ? pt_record_slot(k, F.n_dsph) : F.n_dsph + pt_record_slot(k, F.n_dbox);
+                    uint64_t v = g0[(size_t)oi * W8 + wd];
+                    if (wd == W8 - 1) v = (v & ~0xffff0000ull) | ((uint64_t)(uint32_t)oi << 16);
+                    ld[(size_t)slot * W8 + wd] = v;
+                }
+            }
+        }
         __syncthreads();
     }
     const DevObj *const s_obj = BIG ? B.objs : lds_obj;
@@ -1709,8 +1749,8 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
     const ConstSphPtr g_bs = (ConstSphPtr)(B.bsph);
     const ConstBoxPtr g_bb = (ConstBoxPtr)(B.bbox);
     const ConstIdxPtr g_pl = (ConstIdxPtr)(B.plane_idx);
-    const BroadLists<ConstSphPtr, ConstBoxPtr> BL{g_bs, g_bb, F.n_bsph, F.n_bbox, F.sph_all, F.box_all, F.sph_diel, F.box_diel,
-                                                  lds_kidx, lds_kidx + F.n_bsph};
+    const BroadLists<ConstSphPtr, ConstBoxPtr, RO> BL{g_bs, g_bb, F.n_bsph, F.n_bbox, F.sph_all, F.box_all, F.sph_diel, F.box_diel,
+                                                      lds_kidx, lds_kidx + F.n_bsph, lds_rec, lds_rec + F.n_bsph};
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
     // the shader clock this launch runs at (pt_stats.shader_clock_mhz): the first wave of the launch notes the shader-cycle and the
     // 100 MHz reference counters now and again when it retires (in memory, not in registers: the loop has none to spare)
@@ -2041,8 +2081,9 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                     constexpr bool WIDE_ = (SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE);
                     constexpr bool VERIFY_ = (SCAN == SCAN_VERIFY || SCAN == SCAN_VERIFY_WIDE);
                     const uint32_t all_s = F.n_dsph >= 32 ? 0xffffffffu : ((1u << F.n_dsph) - 1u), all_b = F.n_dbox >= 32 ? 0xffffffffu : ((1u << F.n_dbox) - 1u);
-                    const BroadLists<ConstSphPtr, ConstBoxPtr> BLd{(ConstSphPtr)KA->B.bsph_diel, (ConstBoxPtr)KA->B.bbox_diel, F.n_dsph, F.n_dbox, all_s, all_b, all_s, all_b,
-                                                                   lds_kidx + F.n_bsph + F.n_bbox, lds_kidx + F.n_bsph + F.n_bbox + F.n_dsph};
+                    const BroadLists<ConstSphPtr, ConstBoxPtr, RO> BLd{(ConstSphPtr)KA->B.bsph_diel, (ConstBoxPtr)KA->B.bbox_diel, F.n_dsph, F.n_dbox, all_s, all_b, all_s, all_b,
+                                                                       lds_kidx + F.n_bsph + F.n_bbox, lds_kidx + F.n_bsph + F.n_bbox + F.n_dsph,
+                                                                       lds_rec + F.n_bsph + F.n_bbox, lds_rec + F.n_bsph + F.n_bbox + F.n_dsph};
                     if (WIDE_) scan_broad_narrow_wide<PROF, VERIFY_, 1>(F, g_obj, BLd, g_pl, s_obj, eray, eclip, 1, ebest, etmax, eph);
                     else scan_broad_narrow<PROF, VERIFY_, 1>(F, g_obj, BLd, g_pl, s_obj, eray, eclip, 1, ebest, etmax, eph);
                     if (VERIFY_) {
@@ -2212,6 +2253,8 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
     DevObj *lds_obj = reinterpret_cast<DevObj *>(smem);
     DevMat *lds_mat = reinterpret_cast<DevMat *>(smem + (size_t)F.nobj * sizeof(DevObj));
     int *lds_kidx = reinterpret_cast<int *>(smem + (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat));
+    DevObj *lds_rec = reinterpret_cast<DevObj *>(smem + (((size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
+                                                            (size_t)(F.n_dsph + F.n_dbox) * sizeof(int) + 15) & ~(size_t)15));
     {
         const uint64_t *g0 = reinterpret_cast<const uint64_t *>(B.objs);
         uint64_t *l0 = reinterpret_cast<uint64_t *>(lds_obj);
@@ -2223,6 +2266,20 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
         for (int i = threadIdx.x; i < n1; i += PT_BLOCK) l1[i] = g1[i];
         for (int i = threadIdx.x; i < F.n_dsph; i += PT_BLOCK) lds_kidx[pt_record_slot(i, F.n_dsph)] = B.bsph_diel[i].index;
         for (int i = threadIdx.x; i < F.n_dbox; i += PT_BLOCK) lds_kidx[F.n_dsph + pt_record_slot(i, F.n_dbox)] = B.bbox_diel[i].index;
+        if (!WIDE) {  // the dielectric records' objects again, in record order (BroadLists::rs / rb, see trace_kernel)
+            uint64_t *ld = reinterpret_cast<uint64_t *>(lds_rec);
+            const int nd = F.n_dsph + F.n_dbox, W8 = (int)(sizeof(DevObj) / 8);
+            for (int q = threadIdx.x; q < nd * W8; q += PT_BLOCK) {
+                const int rcd = q / W8, wd = q - rcd * W8;
+                const bool sph = rcd < F.n_dsph;
+                const int k = sph ? rcd : rcd - F.n_dsph;
+                const int oi = sph ? B.bsph_diel[k].index : B.bbox_diel[k].index;
+                const int slot = sph ? pt_record_slot(k, F.n_dsph) : F.n_dsph + pt_record_slot(k, F.n_dbox);
+                uint64_t v = g0[(size_t)oi * W8 + wd];
+                if (wd == W8 - 1) v = (v & ~0xffff0000ull) | ((uint64_t)(uint32_t)oi << 16);
+                ld[(size_t)slot * W8 + wd] = v;
+            }
+        }
         __syncthreads();
     }
     typedef const DevObj __attribute__((address_space(4))) *ConstObjPtr;
@@ -2232,8 +2289,8 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
     const ConstObjPtr g_obj = (ConstObjPtr)(B.objs);
     const ConstIdxPtr g_pl = (ConstIdxPtr)(B.plane_idx);
     const uint32_t all_s = F.n_dsph >= 32 ? 0xffffffffu : ((1u << F.n_dsph) - 1u), all_b = F.n_dbox >= 32 ? 0xffffffffu : ((1u << F.n_dbox) - 1u);
-    const BroadLists<ConstSphPtr, ConstBoxPtr> BL{(ConstSphPtr)B.bsph_diel, (ConstBoxPtr)B.bbox_diel, F.n_dsph, F.n_dbox, all_s, all_b,
-                                                  all_s, all_b, lds_kidx, lds_kidx + F.n_dsph};
+    const BroadLists<ConstSphPtr, ConstBoxPtr, !WIDE> BL{(ConstSphPtr)B.bsph_diel, (ConstBoxPtr)B.bbox_diel, F.n_dsph, F.n_dbox, all_s, all_b,
+                                                         all_s, all_b, lds_kidx, lds_kidx + F.n_dsph, lds_rec, lds_rec + F.n_dsph};
     const uint32_t lane = threadIdx.x & (PT_WAVE - 1);
     typedef const uint32_t __attribute__((address_space(4))) *ConstU32Ptr;
     const uint32_t n_raw = *(ConstU32Ptr)(B.glass.count);

@@ -1485,8 +1485,13 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     sd.lds_bytes = big ? stack_bytes + (size_t)F.bvh_lds_nodes * sizeof(BvhNode)
                        : (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
                              (size_t)(sd.bsph.size() + sd.bbox.size() + sd.bsph_diel.size() + sd.bbox_diel.size()) * sizeof(int);  // (+ the dielectric-only tables of FORM_NESTED)
+    // single-group scans keep the records' objects a second time, in record order (trace_kernel: lds_rec)
+    if (scan == ptk::SCAN_BROAD || scan == ptk::SCAN_VERIFY)
+        sd.lds_bytes = ((sd.lds_bytes + 15) & ~(size_t)15) + (sd.bsph.size() + sd.bbox.size() + sd.bsph_diel.size() + sd.bbox_diel.size()) * sizeof(DevObj);
     sd.glass_lds_bytes = (size_t)F.nobj * sizeof(DevObj) + (size_t)F.nmat * sizeof(DevMat) +
                          (size_t)(sd.bsph_diel.size() + sd.bbox_diel.size()) * sizeof(int);
+    if (scan == ptk::SCAN_BROAD || scan == ptk::SCAN_VERIFY)  // glass_kernel<*, *, false>: the dielectric records' objects in record order
+        sd.glass_lds_bytes = ((sd.glass_lds_bytes + 15) & ~(size_t)15) + (sd.bsph_diel.size() + sd.bbox_diel.size()) * sizeof(DevObj);
     // PTCORE_BVH_LDS_PAD=<bytes>: unused LDS on top of the BVH plan (occupancy experiments: 4 blocks per CU fit 40 KiB each)
     if (const char *e = std::getenv("PTCORE_BVH_LDS_PAD"))
         if (big) sd.lds_bytes += (size_t)std::max(0, std::min(120 * 1024, std::atoi(e)));
