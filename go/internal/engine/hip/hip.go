@@ -49,6 +49,9 @@ var (
 )
 
 // SetDevices selects how many GPUs (ordinals 0..n-1) the frame is tiled over.
+// The tiles of a frame are collected on device 0 by peer copies over xGMI, or -- with
+// PTCORE_GATHER=rccl in the environment when the context is created -- by grouped RCCL
+// send / receive (libptcore loads librccl.so itself in that case; nothing to link here).
 func SetDevices(n int) {
 	mu.Lock()
 	defer mu.Unlock()
