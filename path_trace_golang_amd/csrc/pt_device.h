@@ -161,6 +161,9 @@ struct DevFrame {
                          // are clipped against the scene cube first (the FP32 bounds were analysed for origins within 4 B)
     double margin;       // m = B/4096: inflation of every FP32 bound
     uint64_t seed_key;   // ptm::seed_key(seed)
+    double plane0_y;     // planes_y and n_plane == 1 (every scene file of the reference): the plane's point.y, its object index and kind --
+    int32_t plane0_index;  // the scans then take the plane from the argument block instead of through plane_idx[] -> objs[] (two dependent
+    int32_t plane0_kind;   // scalar loads at the head of every scan); plane0_index < 0: no such plane
     double inv_width;    // 1/(W-1)  renderer.go:95
     double inv_height;   // 1/(H-1)  renderer.go:96
     double height_m1;    // H-1      renderer.go:98

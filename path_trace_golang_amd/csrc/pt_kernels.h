@@ -70,6 +70,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the p
 #define PT_BROAD_UNROLL 4  // records per turn of the broad-phase loops of the single-group scan: all their scalar loads are issued before the first
                            // record is used.  Same box, C4: 530.6 / 526.8 / 524.4 ms per frame for 1 / 2 / 4 (profiles/r04_broad_unroll_ab.txt)
 #endif
+#ifndef PT_PLANE0
+#define PT_PLANE0 1  // single-group scan: the scene's one plane from the argument block (A/B: -DPT_PLANE0=0)
+#endif
 #ifndef PT_NESTED_WAVES
 #define PT_NESTED_WAVES PT_FLAT_WAVES  // ... and the pass behind the split rounds (FORM_NESTED)
 #endif
@@ -556,21 +559,52 @@ __host__ __device__ __forceinline__ int pt_record_slot(int i, int n) {
     return g + (cnt - 1 - (i - g));
 }
 
+// The scene's one plane (normal (0, 1, 0)) as the scans take it from the argument block: DevFrame::plane0_*, read by the caller right before
+// the scan (from the kernarg segment, where the kernel re-reads such things) so that it does not sit in scalar registers through the loops.
+struct Plane0 {
+    double y;
+    int32_t index;  // < 0: no such plane, the scan goes through plane_idx[] -> objs[]
+    int32_t kind;
+};
+
 // Broad phase in FP32 over inflated bounds + exact FP64 narrow phase over the survivors.
 // MODE: 0 closest hit, 1 exit search, -1 decided per lane by `mode_rt`.
 template <bool PROF, bool DBG, int MODE, typename ObjPtr, typename BLT, typename IdxPtr>
 __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_obj, const BLT &BL, IdxPtr g_pl,
                                                   const DevObj *s_obj, const RayD &r, const Clip &clip,
-                                                  int mode_rt, int &best, double &tmax, const ProfHooks &ph) {
+                                                  int mode_rt, int &best, double &tmax, const ProfHooks &ph, const Plane0 P0 = Plane0{0.0, -1, 0}) {
     const int mode = MODE < 0 ? mode_rt : MODE;
     const double tmin = mode ? 0.0001 : 0.001;
     tmax = ptm::max_float64();
     best = -1;
     bool best_is_box = false;
     const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+    struct SphRec { float cx, cy, cz, rm2; };
+    // (requesting the first four sphere records here, ahead of the plane test and the FP32 set-up, was measured: +1.2 % time -- the sixteen
+    // scalar registers they hold meanwhile cost more than the wait they save; profiles/r04_plane0_ab.txt)
 
     // ---- planes: infinite, always tested exactly (wave-uniform, scalar loads)
     PH_BEGIN(SEC_PLANE)
+#if PT_PLANE0
+    if (P0.index >= 0) {
+        // the one plane of the scene, normal (0, 1, 0), straight from the argument block (see DevFrame::plane0_y)
+        const int i = P0.index;
+        const bool pdiel = (P0.kind & 0x100) != 0;
+        if (!(MODE == 1 && !pdiel)) {
+            double t = 0;
+            bool acc = plane_exact_y(P0.y, r, tmin, tmax, t);
+            if (MODE < 0 && mode != 0 && !pdiel) acc = false;
+            if (acc) {
+                if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
+                              : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(g_obj[i], KIND_PLANE, r, t))) {
+                    best = i;
+                    tmax = t;
+                    best_is_box = false;
+                }
+            }
+        }
+    } else
+#endif
     for (int k = 0; k < F.n_plane; k++) {
         const int i = g_pl[k];
         const auto &o = g_obj[i];
@@ -627,7 +661,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
     };
     {
         int k = 0;
-        struct Rec { float cx, cy, cz, rm2; };
+        typedef SphRec Rec;
 #if PT_BROAD_UNROLL >= 4
         for (; k + 3 < BL.n_bsph; k += 4) {
             const auto &a0 = BL.bs[k];
@@ -751,7 +785,7 @@ __device__ __forceinline__ void scan_broad_narrow(const DevFrame &F, ObjPtr g_ob
 template <bool PROF, bool DBG, int MODE, typename ObjPtr, typename BLT, typename IdxPtr>
 __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr g_obj, const BLT &BL, IdxPtr g_pl,
                                                        const DevObj *s_obj, const RayD &r, const Clip &clip,
-                                                       int mode_rt, int &best, double &tmax, const ProfHooks &ph) {
+                                                       int mode_rt, int &best, double &tmax, const ProfHooks &ph, const Plane0 P0 = Plane0{0.0, -1, 0}) {
     const int mode = MODE < 0 ? mode_rt : MODE;
     const double tmin = mode ? 0.0001 : 0.001;
     tmax = ptm::max_float64();
@@ -761,6 +795,20 @@ __device__ __forceinline__ void scan_broad_narrow_wide(const DevFrame &F, ObjPtr
     const double ya = div_recip(a);
 
     PH_BEGIN(SEC_PLANE)
+#if PT_PLANE0
+    if (P0.index >= 0) {  // the scene's one plane from the argument block (see scan_broad_narrow)
+        const int i = P0.index;
+        double t = 0;
+        if (!(mode != 0 && !(P0.kind & 0x100)) && plane_exact_y(P0.y, r, tmin, tmax, t)) {
+            if (mode == 0 ? wins(0, false, i, t, best, best_is_box, tmax)
+                          : (wins(1, false, i, t, best, best_is_box, tmax) && exit_candidate_ok(g_obj[i], KIND_PLANE, r, t))) {
+                best = i;
+                tmax = t;
+                best_is_box = false;
+            }
+        }
+    } else
+#endif
     for (int k = 0; k < F.n_plane; k++) {
         const int i = g_pl[k];
         const auto &o = g_obj[i];
@@ -1953,9 +2001,11 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                     trav.live = false;  // a complete answer: whatever walk was pending is obsolete
                 } else {
                     if (WIDE)
-                        scan_broad_narrow_wide<PROF, VERIFY, (SPLIT || NEST) ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
+                        scan_broad_narrow_wide<PROF, VERIFY, (SPLIT || NEST) ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph,
+                                                                                       Plane0{KA->F.plane0_y, KA->F.plane0_index, KA->F.plane0_kind});
                     else if (BITMASK)
-                        scan_broad_narrow<PROF, VERIFY, (SPLIT || NEST) ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph);
+                        scan_broad_narrow<PROF, VERIFY, (SPLIT || NEST) ? 0 : -1>(F, g_obj, BL, g_pl, s_obj, ray, clip, mode, best, tmax, ph,
+                                                                                  Plane0{KA->F.plane0_y, KA->F.plane0_index, KA->F.plane0_kind});
                     else if ((fat = !trav.live && clip.far && !clip.miss && clip.infl * 16.0 > F.scene_bound))
                         scanned = false;  // no walk for this one: the whole wave scans the world for it, below
                     else if (__ballot(clip.far || !bvh_ray_trusted(F, ray, clip, a_)) != 0)
@@ -2084,8 +2134,10 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                     const BroadLists<ConstSphPtr, ConstBoxPtr, RO> BLd{(ConstSphPtr)KA->B.bsph_diel, (ConstBoxPtr)KA->B.bbox_diel, F.n_dsph, F.n_dbox, all_s, all_b, all_s, all_b,
                                                                        lds_kidx + F.n_bsph + F.n_bbox, lds_kidx + F.n_bsph + F.n_bbox + F.n_dsph,
                                                                        lds_rec + F.n_bsph + F.n_bbox, lds_rec + F.n_bsph + F.n_bbox + F.n_dsph};
-                    if (WIDE_) scan_broad_narrow_wide<PROF, VERIFY_, 1>(F, g_obj, BLd, g_pl, s_obj, eray, eclip, 1, ebest, etmax, eph);
-                    else scan_broad_narrow<PROF, VERIFY_, 1>(F, g_obj, BLd, g_pl, s_obj, eray, eclip, 1, ebest, etmax, eph);
+                    if (WIDE_) scan_broad_narrow_wide<PROF, VERIFY_, 1>(F, g_obj, BLd, g_pl, s_obj, eray, eclip, 1, ebest, etmax, eph,
+                                                                        Plane0{KA->F.plane0_y, KA->F.plane0_index, KA->F.plane0_kind});
+                    else scan_broad_narrow<PROF, VERIFY_, 1>(F, g_obj, BLd, g_pl, s_obj, eray, eclip, 1, ebest, etmax, eph,
+                                                             Plane0{KA->F.plane0_y, KA->F.plane0_index, KA->F.plane0_kind});
                     if (VERIFY_) {
                         int best2;
                         double tmax2;
@@ -2112,6 +2164,7 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 // one whole 32-byte record per job: lanes finish at different times, so a [3][njobs] layout
                 // would dirty three partly written sectors per job
                 const auto kb = &KA->B;
+                // (requesting the pointer ahead of the shading code instead of here was measured: nothing, profiles/r04_plane0_ab.txt)
                 reinterpret_cast<double4 *>(kb->L)[job] = make_double4(Tx * termx, Ty * termy, Tz * termz, 0.0);
                 if (STATS) {
                     kb->job_seg[job] = j_seg;
@@ -2363,8 +2416,10 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
                     if (__ballot(!tame) != 0) {
                         scan_uniform(F, g_obj, ray, 1, ebest, etmax);
                     } else {
-                        if (WIDE) scan_broad_narrow_wide<false, VERIFY, 1>(F, g_obj, BL, g_pl, lds_obj, ray, clip, 1, ebest, etmax, ph);
-                        else scan_broad_narrow<false, VERIFY, 1>(F, g_obj, BL, g_pl, lds_obj, ray, clip, 1, ebest, etmax, ph);
+                        if (WIDE) scan_broad_narrow_wide<false, VERIFY, 1>(F, g_obj, BL, g_pl, lds_obj, ray, clip, 1, ebest, etmax, ph,
+                                                                           Plane0{pt_launder(ka)->F.plane0_y, pt_launder(ka)->F.plane0_index, pt_launder(ka)->F.plane0_kind});
+                        else scan_broad_narrow<false, VERIFY, 1>(F, g_obj, BL, g_pl, lds_obj, ray, clip, 1, ebest, etmax, ph,
+                                                                 Plane0{pt_launder(ka)->F.plane0_y, pt_launder(ka)->F.plane0_index, pt_launder(ka)->F.plane0_kind});
                         if (VERIFY) {
                             int best2;
                             double tmax2;

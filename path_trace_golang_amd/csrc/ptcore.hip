@@ -479,6 +479,15 @@ void build_broad(const std::vector<DevObj> &world, SceneData &fr) {
         // (inf * 0 = NaN makes the reference's t a NaN, which its range test accepts)
         if (!(std::isfinite(o.a[0]) && std::isfinite(o.a[1]) && std::isfinite(o.a[2]))) F.planes_y = 0;
     }
+    F.plane0_index = -1;
+    F.plane0_y = 0.0;
+    F.plane0_kind = 0;
+    if (F.planes_y && fr.plane_idx.size() == 1) {
+        const DevObj &o = world[(size_t)fr.plane_idx[0]];
+        F.plane0_index = fr.plane_idx[0];
+        F.plane0_y = o.a[1];
+        F.plane0_kind = o.kind;
+    }
     F.n_dsph = (int32_t)fr.bsph_diel.size();
     F.n_dbox = (int32_t)fr.bbox_diel.size();
     F.broad_ok = (fr.bsph.size() <= 32 && fr.bbox.size() <= 32) ? 1 : (fr.bsph.size() <= 128 && fr.bbox.size() <= 128) ? 2 : 0;
