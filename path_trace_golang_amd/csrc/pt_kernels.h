@@ -70,6 +70,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the p
 #define PT_BROAD_UNROLL 4  // records per turn of the broad-phase loops of the single-group scan: all their scalar loads are issued before the first
                            // record is used.  Same box, C4: 530.6 / 526.8 / 524.4 ms per frame for 1 / 2 / 4 (profiles/r04_broad_unroll_ab.txt)
 #endif
+#ifndef PT_CLIP32
+#define PT_CLIP32 1  // bitmask scans: the scene-cube clip in FP32 with an explicit error term (A/B: -DPT_CLIP32=0)
+#endif
 #ifndef PT_PLANE0
 #define PT_PLANE0 1  // single-group scan: the scene's one plane from the argument block (A/B: -DPT_PLANE0=0)
 #endif
@@ -544,6 +547,46 @@ __device__ __forceinline__ float pt_vmin3(float a, float b, float c) {
     float d;
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
+}
+
+// clip_ray in FP32 with an explicit error term, for the bitmask scans: they never need `infl` (a far ray
+// takes the reference's plain loop there), and everything else clip_ray returns only has to err on the safe side:
+//   * a slab parameter (+-Bs - o) * (1 / d) in FP32 carries a relative error below 3.6e-7 of (|o| + Bs) |1 / d| (two conversions, one
+//     subtraction, v_rcp_f32 at 1 ulp, one product); E = the largest of the three per-axis bounds at 5e-7;
+//   * miss is said only when te - E > tx + E (or tx + E < tmin): a ray wrongly called a hit is merely scanned; one wrongly called a miss would
+//     have to pass within E |d| <= 5e-7 reach of the cube, which keeps B / 512 - m = 1.7e-3 B of clearance around every bound, and reach
+//     is below 2 035 B whenever the ray is not `far` (5e-7 * 2 035 B = 1.0e-3 B);
+//   * ts (where the FP32 tests start) and te (compared with tmax) are LOWER bounds of the entry parameter: starting a little early is
+//     always safe, the point stays within 1.1e-3 B of the cube, far inside the 4 B the FP32 bounds were analysed for;
+//   * far is decided on a reach rounded up.
+// 25 FP32 instructions (three v_rcp_f32 the box records need anyway) where clip_ray takes 50 FP64 ones and three v_rcp_f64.
+__device__ __forceinline__ Clip clip_ray32(const DevFrame &F, const RayD &r, double tmin) {
+    Clip c{0.0, 0.0, 0.0, false, false};
+    const double Cb = F.clip_bound;
+    if (!(ptm::f_abs(r.ox) <= Cb && ptm::f_abs(r.oy) <= Cb && ptm::f_abs(r.oz) <= Cb)) {
+        const float Bf = (float)F.scene_bound * 1.0000002f;  // >= Bs
+        const float fox = (float)r.ox, foy = (float)r.oy, foz = (float)r.oz;
+        const float fdx = (float)r.dx, fdy = (float)r.dy, fdz = (float)r.dz;
+        const float ix = __builtin_amdgcn_rcpf(fdx), iy = __builtin_amdgcn_rcpf(fdy), iz = __builtin_amdgcn_rcpf(fdz);
+        const float x0 = (-Bf - fox) * ix, x1 = (Bf - fox) * ix;
+        const float y0 = (-Bf - foy) * iy, y1 = (Bf - foy) * iy;
+        const float z0 = (-Bf - foz) * iz, z1 = (Bf - foz) * iz;
+        // (v_min / v_max skip the NaN of a 0 * inf slab boundary: that slab then constrains nothing, as in clip_ray)
+        const float te = pt_vmax3(pt_vmin(x0, x1), pt_vmin(y0, y1), pt_vmin(z0, z1));
+        const float tx = pt_vmin3(pt_vmax(x0, x1), pt_vmax(y0, y1), pt_vmax(z0, z1));
+        const float E = 5.0e-7f * pt_vmax3((__builtin_fabsf(fox) + Bf) * __builtin_fabsf(ix), (__builtin_fabsf(foy) + Bf) * __builtin_fabsf(iy),
+                                           (__builtin_fabsf(foz) + Bf) * __builtin_fabsf(iz));
+        const float reach = (__builtin_fabsf(fox) + __builtin_fabsf(foy) + __builtin_fabsf(foz) +
+                             (__builtin_fabsf(fdx) + __builtin_fabsf(fdy) + __builtin_fabsf(fdz)) * __builtin_fabsf(te)) * 1.00001f;
+        // (NaN or infinite quantities land on `far`: the plain loop)
+        c.far = !(reach * 3.0e-8f <= (float)(F.margin * 0.2499));
+        const float te_lo = te - E, tx_hi = tx + E;
+        c.miss = te_lo > tx_hi || tx_hi < (float)tmin * 0.99f;
+        if (c.far) c.miss = false;
+        c.te = (double)te_lo;
+        c.ts = (te_lo > 0.0f && !c.miss) ? (double)te_lo : 0.0;
+    }
+    return c;
 }
 
 // Candidate masks are built by shifting: mask = 2 * mask + keep, keep = !(a < b) -- one compare and ONE v_addc_co_u32 (the
@@ -1867,7 +1910,9 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
         SEC_BEGIN(SEC_ITER)
         // ------------------------------------------------------------ regeneration
         const uint64_t need = __ballot(!active);
-        if (need != 0) {
+        // (PTCORE_REFILL_MIN: refilling only once several lanes are idle -- VERDICT r03 item 3 -- was swept and lost at every value: the scan costs a wave the
+        // same whatever the number of its lanes that take part, so an idle lane is a lost segment; profiles/r04_refill_min.txt)
+        if (need != 0 && (F.refill_min <= 1u || (uint32_t)__popcll(need) >= F.refill_min)) {
             if (cur >= end && !exhausted) {
                 // (Round 4 tried guided claims -- a claim's size falling with what is left of the queue, 1 / (4 x waves) of it down to one
                 // row of 64, so that the waves of a launch end together: C4 533.3 against 529.8 ms per frame at 4 passes, 559.1 against
@@ -1989,9 +2034,9 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 // scan, which IS the reference's loop.  Rays from astronomically far away (clip_ray) break the
                 // second: the bitmask strategy treats them the same way, the BVH widens its bounds for them.
                 const double a_ = dx * dx + dy * dy + dz * dz;
-                const Clip clip = clip_ray(F, ray, mode ? 0.0001 : 0.001);
                 constexpr bool WIDE = (SCAN == SCAN_BROAD_WIDE || SCAN == SCAN_VERIFY_WIDE);
                 constexpr bool BITMASK = (SCAN == SCAN_BROAD || SCAN == SCAN_VERIFY || WIDE);
+                const Clip clip = (BITMASK && PT_CLIP32) ? clip_ray32(F, ray, mode ? 0.0001 : 0.001) : clip_ray(F, ray, mode ? 0.0001 : 0.001);
                 const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) &&
                                   (ptm::f_abs(oy) <= 1e100) && (ptm::f_abs(oz) <= 1e100) && !(BITMASK && clip.far);
                 const bool plain = __ballot(!tame) != 0;
@@ -2121,7 +2166,7 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 int ebest = -1;
                 double etmax = 0;
                 const double ea = dx * dx + dy * dy + dz * dz;
-                const Clip eclip = clip_ray(F, eray, 0.0001);
+                const Clip eclip = PT_CLIP32 ? clip_ray32(F, eray, 0.0001) : clip_ray(F, eray, 0.0001);
                 // same guards as the main scan: untamed or far-away rays take the reference's plain loop
                 const bool etame = (ea >= 1e-100) && (ea <= 1e100) && (ptm::f_abs(ox) <= 1e100) && (ptm::f_abs(oy) <= 1e100) &&
                                    (ptm::f_abs(oz) <= 1e100) && !eclip.far;
@@ -2410,7 +2455,7 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
                     double etmax = 0;
                     // same guards as the trace kernel: untamed or far-away rays take the reference's plain loop
                     const double a_ = dx * dx + dy * dy + dz * dz;
-                    const Clip clip = clip_ray(F, ray, 0.0001);
+                    const Clip clip = PT_CLIP32 ? clip_ray32(F, ray, 0.0001) : clip_ray(F, ray, 0.0001);
                     const bool tame = (a_ >= 1e-100) && (a_ <= 1e100) && (ptm::f_abs(ox) <= 1e100) && (ptm::f_abs(oy) <= 1e100) &&
                                       (ptm::f_abs(oz) <= 1e100) && !clip.far;
                     if (__ballot(!tame) != 0) {
