@@ -155,7 +155,7 @@ struct DevFrame {
     uint32_t sph_all, box_all;    // (1 << n_bsph) - 1, (1 << n_bbox) - 1
     uint32_t sph_diel, box_diel;  // records whose object is dielectric (exit searches)
     float origin_bound;  // rays whose origin leaves [-origin_bound, origin_bound]^3 keep every candidate
-    uint32_t refill_min;  // PTCORE_REFILL_MIN (A/B): a wave takes new jobs only once this many of its lanes are idle (1 = whenever one is)
+    float pad_f;
     double scene_bound;  // Bs: every finite object (inflated) lies inside [-Bs, Bs]^3
     double clip_bound;   // 3.5 B: rays that start inside [-clip_bound, clip_bound]^3 are scanned from their origin, the others
                          // are clipped against the scene cube first (the FP32 bounds were analysed for origins within 4 B)

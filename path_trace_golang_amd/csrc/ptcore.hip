@@ -1483,8 +1483,6 @@ int32_t scene_prepare(pt_ctx *ctx, const pt_scene *scene) {
     F.debug_drop = 0;  // PTCORE_DEBUG_DROP=<mask>: the verify instantiations of the bitmask scans lose these candidate bits
     if (const char *e = std::getenv("PTCORE_DEBUG_DROP")) F.debug_drop = (uint32_t)std::strtoul(e, nullptr, 0);
     if (const char *e = std::getenv("PTCORE_BVH_MIN_LANES")) F.bvh_min_lanes = std::max(0, std::min(64, std::atoi(e)));
-    F.refill_min = 1;
-    if (const char *e = std::getenv("PTCORE_REFILL_MIN")) F.refill_min = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     F.bvh_leaf_single = 1;
     if (const char *e = std::getenv("PTCORE_BVH_LEAF_SINGLE")) F.bvh_leaf_single = std::atoi(e) != 0;
     F.bvh_node_min = 16;
