@@ -1515,6 +1515,135 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_lens_kernel(const DevFrame F,
     }
 }
 
+// The same with the wave's jobs as ONE pool for the rejection walk (round 4).  Walking down a column, a wave waits for the largest
+// sum of attempts over its columns -- ten wave-level attempts for two rows where the jobs need 3.8 on average.  Here the lane whose
+// sample was accepted takes the next job of the pool nobody has started (ballot + mbcnt rank past a wave-uniform cursor), so the
+// wave's attempts are the pool's total over 64 lanes plus one job's tail: 6 per two rows with four rows in the pool.  The point on
+// the focus plane stays in the registers of the lane that computes it in (A) and uses it in (C); LDS holds what crosses lanes --
+// stream state, accepted sample, draw count (26 B per job: four rows = 26 KB per block, six blocks per CU as before).
+#ifndef PT_RG_POOL_ROWS
+#define PT_RG_POOL_ROWS 4
+#endif
+__global__ __launch_bounds__(PT_BLOCK) void raygen_lens_pool_kernel(const DevFrame F, const DevCamera cam, double *__restrict__ ray,
+                                                                      unsigned long long *__restrict__ ray_rng,
+                                                                      uint16_t *__restrict__ ray_ndraw) {
+    constexpr uint32_t R = PT_RG_POOL_ROWS, NJ = R * PT_WAVE;  // jobs in a wave's pool
+    __shared__ unsigned long long s_rs[PT_BLOCK / PT_WAVE][NJ];
+    __shared__ double s_rx[PT_BLOCK / PT_WAVE][NJ], s_ry[PT_BLOCK / PT_WAVE][NJ];
+    __shared__ uint16_t s_nd[PT_BLOCK / PT_WAVE][NJ];  // draws so far, saturating at 0xfffe; 0xffff: pixel outside the frame, or no such job
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (PT_WAVE - 1), wib = tid >> 6;
+    const uint32_t wave = (blockIdx.x * PT_BLOCK + tid) >> 6;
+    const uint32_t row0 = wave * R;  // rows of 64 consecutive jobs
+    unsigned long long *const p_rs = s_rs[wib];
+    double *const p_rx = s_rx[wib], *const p_ry = s_ry[wib];
+    uint16_t *const p_nd = s_nd[wib];
+    // ---- A: everything up to the lens sample, row by row (lockstep)
+    double ax[R], ay[R], az[R];
+#pragma unroll
+    for (uint32_t k = 0; k < R; k++) {
+        const uint32_t myjob = (row0 + k) * 64u + lane;
+        uint16_t nd0 = 0xffffu;
+        ax[k] = 0; ay[k] = 0; az[k] = 0;
+        if (myjob < F.njobs) {
+            const uint32_t p = myjob & 63u;
+            const uint32_t q = myjob >> 6;
+            const uint32_t blk = q / F.S;
+            const uint32_t sl = q - blk * F.S;
+            const uint32_t lt = blk >> 4, sb = blk & 15u;
+            const uint32_t t = (uint32_t)F.shard_index + lt * (uint32_t)F.shard_count;
+            const uint32_t ty = t / (uint32_t)F.ntx, tx = t - ty * (uint32_t)F.ntx;
+            const uint32_t x = tx * 32u + (sb & 3u) * 8u + (p & 7u);
+            const uint32_t y = ty * 32u + (sb >> 2) * 8u + (p >> 3);
+            if (x < (uint32_t)F.width && y < (uint32_t)F.height) {
+                const uint64_t pixel = (uint64_t)y * (uint64_t)(uint32_t)F.width + (uint64_t)x;
+                uint64_t rs = ptm::stream_init(F.seed_key, pixel, (uint64_t)(F.s0 + sl));
+                const double xi_u = ptm::stream_next(rs);
+                const double xi_v = ptm::stream_next(rs);
+                const double u = ((double)x + xi_u) * F.inv_width;
+                const double vv = ((F.height_m1 - (double)y) + xi_v) * F.inv_height;
+                const double tx_ = cam.lower_left[0] + cam.horizontal[0] * u;
+                const double ty_ = cam.lower_left[1] + cam.horizontal[1] * u;
+                const double tz_ = cam.lower_left[2] + cam.horizontal[2] * u;
+                ax[k] = tx_ + cam.vertical[0] * vv;
+                ay[k] = ty_ + cam.vertical[1] * vv;
+                az[k] = tz_ + cam.vertical[2] * vv;
+                p_rs[k * 64u + lane] = rs;
+                nd0 = 2;
+            }
+        }
+        p_nd[k * 64u + lane] = nd0;
+    }
+    // (only this wave touches its pool, and a wave's LDS operations complete in order: a fence for the compiler, no barrier)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // ---- B: the rejection walk over the pool
+    {
+        uint32_t j = lane;   // the job this lane works on
+        uint32_t next = 64;  // first job of the pool nobody has started (wave-uniform)
+        uint32_t nd = p_nd[j];
+        uint64_t rs = nd != 0xffffu ? p_rs[j] : 0;
+        for (;;) {
+            const bool live = j < NJ;
+            if (__ballot(live) == 0) break;
+            bool done = false;
+            if (live) {
+                done = nd == 0xffffu;  // nothing to draw for this job
+                if (!done) {
+                    const double d0 = ptm::stream_next(rs), d1 = ptm::stream_next(rs), d2 = ptm::stream_next(rs);
+                    nd = nd + 3u < 0xfffeu ? nd + 3u : 0xfffeu;
+                    const double rx = d0 * 2 - 1, ry = d1 * 2 - 1, rz = d2 * 2 - 1;
+                    const double lenSq = rx * rx + ry * ry + rz * rz;
+                    if (!(lenSq >= 1.0)) {  // accepted (randomInUnitSphere keeps drawing while lenSq >= 1)
+                        p_rx[j] = rx;
+                        p_ry[j] = ry;
+                        p_rs[j] = rs;
+                        p_nd[j] = (uint16_t)nd;
+                        done = true;
+                    }
+                }
+            }
+            const uint64_t m = __ballot(done);
+            if (m) {
+                if (done) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    j = next + rank;
+                    if (j < NJ) {
+                        nd = p_nd[j];
+                        if (nd != 0xffffu) rs = p_rs[j];
+                    }
+                }
+                next += (uint32_t)__popcll(m);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // ---- C: lens offset, ray, coalesced stores (lockstep)
+    const size_t nj = F.njobs;
+#pragma unroll
+    for (uint32_t k = 0; k < R; k++) {
+        const uint32_t myjob = (row0 + k) * 64u + lane;
+        if (myjob >= F.njobs) continue;
+        const uint32_t nd = p_nd[k * 64u + lane];
+        if (nd == 0xffffu) {
+            PT_ST_NT(1, ray_ndraw[myjob], 0xffffu);
+            continue;
+        }
+        const double rx = p_rx[k * 64u + lane] * cam.lens_radius;
+        const double ry = p_ry[k * 64u + lane] * cam.lens_radius;
+        const double offx = cam.u[0] * rx + cam.v[0] * ry;
+        const double offy = cam.u[1] * rx + cam.v[1] * ry;
+        const double offz = cam.u[2] * rx + cam.v[2] * ry;
+        PT_ST_NT(1, ray[myjob], cam.origin[0] + offx);
+        PT_ST_NT(1, ray[nj + myjob], cam.origin[1] + offy);
+        PT_ST_NT(1, ray[2 * nj + myjob], cam.origin[2] + offz);
+        PT_ST_NT(1, ray[3 * nj + myjob], (ax[k] - cam.origin[0]) - offx);
+        PT_ST_NT(1, ray[4 * nj + myjob], (ay[k] - cam.origin[1]) - offy);
+        PT_ST_NT(1, ray[5 * nj + myjob], (az[k] - cam.origin[2]) - offz);
+        PT_ST_NT(1, ray_rng[myjob], p_rs[k * 64u + lane]);
+        PT_ST_NT(1, ray_ndraw[myjob], (uint16_t)nd);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Shading pieces shared by trace_kernel (all-in-one form) and glass_kernel.  Every expression is the reference's,
 // in the reference's association order.

@@ -1084,7 +1084,12 @@ int32_t dev_step(pt_ctx *ctx, Device &d, uint32_t s0, uint32_t S) {
         if (int32_t rc = dev_events(d, d.ev_raygen, d.n_raygen + 1)) return rc;
         EventPair &eg = d.ev_raygen[d.n_raygen++];
         HIP_TRY(hipEventRecord(eg.a, d.stream));
-        if (fr.cam.lens_radius > 0 && !std::getenv("PTCORE_RAYGEN_SIMPLE"))  // thin lens: the rejection loop, PT_RG_ROWS jobs per lane
+        const char *rg_form = std::getenv("PTCORE_RAYGEN");  // A/B: "column" = round 2's walk down a lane's column, "simple" = one job per lane
+        const bool rg_simple = std::getenv("PTCORE_RAYGEN_SIMPLE") || (rg_form && !std::strcmp(rg_form, "simple"));
+        if (fr.cam.lens_radius > 0 && !rg_simple && !(rg_form && !std::strcmp(rg_form, "column")))  // thin lens: the rejection loop over a wave's pool of jobs
+            hipLaunchKernelGGL(ptk::raygen_lens_pool_kernel, dim3((F.njobs + PT_BLOCK * PT_RG_POOL_ROWS - 1) / (PT_BLOCK * PT_RG_POOL_ROWS)), dim3(PT_BLOCK), 0,
+                               d.stream, F, fr.cam, d.ray.p, d.ray_rng.p, d.ray_ndraw.p);
+        else if (fr.cam.lens_radius > 0 && !rg_simple)
             hipLaunchKernelGGL(ptk::raygen_lens_kernel, dim3((F.njobs + PT_BLOCK * PT_RG_ROWS - 1) / (PT_BLOCK * PT_RG_ROWS)), dim3(PT_BLOCK), 0,
                                d.stream, F, fr.cam, d.ray.p, d.ray_rng.p, d.ray_ndraw.p);
         else

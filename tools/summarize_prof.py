@@ -23,7 +23,7 @@ def klass(name: str):
     if m:
         # 4th parameter: FORM (0 all-in-one, 1 split, 2 nested exit search); a bool before round 4
         return "trace_split" if m.group(4) in ("true", "1") else "trace_nested" if m.group(4) == "2" else "trace_allinone"
-    for k in ("glass_kernel", "raygen_lens_kernel", "raygen_kernel", "resolve_kernel", "wf_", "untile_kernel"):
+    for k in ("glass_kernel", "raygen_lens_pool_kernel", "raygen_lens_kernel", "raygen_kernel", "resolve_kernel", "wf_", "untile_kernel"):
         if k in name:
             return k.replace("_kernel", "")
     return None
