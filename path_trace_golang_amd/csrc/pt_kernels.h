@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_kernel(const DevFrame F, cons
     if (myjob >= F.njobs) return;
     // job -> (tile, sub-block, sample, pixel)
     const uint32_t p = myjob & 63u;
-    const uint32_t q = myjob >> 6;
+    const uint32_t q = __builtin_amdgcn_readfirstlane(myjob >> 6);  // the wave's row of 64 jobs: tile, sub-block and sample are wave-uniform (scalar unit)
     const uint32_t blk = q / F.S;
     const uint32_t sl = q - blk * F.S;
     const uint32_t lt = blk >> 4, sb = blk & 15u;
@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_lens_kernel(const DevFrame F,
     __shared__ uint32_t s_nd[PT_RG_ROWS][PT_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (PT_WAVE - 1);
-    const uint32_t wave = (blockIdx.x * PT_BLOCK + tid) >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * PT_BLOCK + tid) >> 6);
     const uint32_t row0 = wave * PT_RG_ROWS;  // rows of 64 consecutive jobs
     // ---- A: everything up to the lens sample, row by row
 #pragma unroll
@@ -1437,8 +1437,8 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_lens_kernel(const DevFrame F,
         const uint32_t myjob = (row0 + (uint32_t)k) * 64u + lane;
         uint32_t nd0 = 0xffffffffu;
         if (myjob < F.njobs) {
-            const uint32_t p = myjob & 63u;
-            const uint32_t q = myjob >> 6;
+            const uint32_t p = lane;
+            const uint32_t q = row0 + (uint32_t)k;
             const uint32_t blk = q / F.S;
             const uint32_t sl = q - blk * F.S;
             const uint32_t lt = blk >> 4, sb = blk & 15u;
@@ -1533,23 +1533,23 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_lens_pool_kernel(const DevFra
     __shared__ uint16_t s_nd[PT_BLOCK / PT_WAVE][NJ];  // draws so far, saturating at 0xfffe; 0xffff: pixel outside the frame, or no such job
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (PT_WAVE - 1), wib = tid >> 6;
-    const uint32_t wave = (blockIdx.x * PT_BLOCK + tid) >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * PT_BLOCK + tid) >> 6);  // (said so: a row's tile, sub-block and sample -- two integer divisions -- are then the scalar unit's)
     const uint32_t row0 = wave * R;  // rows of 64 consecutive jobs
     unsigned long long *const p_rs = s_rs[wib];
     double *const p_rx = s_rx[wib], *const p_ry = s_ry[wib];
     uint16_t *const p_nd = s_nd[wib];
     // ---- A: everything up to the lens sample, row by row (lockstep)
     double ax[R], ay[R], az[R];
+    const uint32_t blk0 = row0 / F.S, sl0 = row0 - blk0 * F.S;  // one division per wave, the rows after the first follow by carry
 #pragma unroll
     for (uint32_t k = 0; k < R; k++) {
         const uint32_t myjob = (row0 + k) * 64u + lane;
         uint16_t nd0 = 0xffffu;
         ax[k] = 0; ay[k] = 0; az[k] = 0;
         if (myjob < F.njobs) {
-            const uint32_t p = myjob & 63u;
-            const uint32_t q = myjob >> 6;
-            const uint32_t blk = q / F.S;
-            const uint32_t sl = q - blk * F.S;
+            const uint32_t p = lane;
+            uint32_t sl = sl0 + k, blk = blk0;  // row0 + k = blk * S + sl
+            while (sl >= F.S) { sl -= F.S; blk++; }
             const uint32_t lt = blk >> 4, sb = blk & 15u;
             const uint32_t t = (uint32_t)F.shard_index + lt * (uint32_t)F.shard_count;
             const uint32_t ty = t / (uint32_t)F.ntx, tx = t - ty * (uint32_t)F.ntx;
