@@ -2118,6 +2118,9 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 // the ray is fetched before nd is looked at (an out-of-frame job's slots exist too, their content is not used): one
                 // round trip to memory per refill instead of two in a row
                 // (assigned here, not under the test: the compiler would sink the loads back below it)
+                // (Round 4 also tried to have these lines in L2 by then -- a wave requesting the rays of its claim 64 - 128 jobs ahead of its
+                // refills, 29 fire-and-forget `global_load_lds` per 64 jobs: trace passes 436 -> 445 ms per C4 frame, profiles/r04_refill_prefetch_ab.txt;
+                // the other five waves of the SIMD cover this round trip already, and the prefetch costs a uniform branch and address arithmetic on every refill.)
                 const size_t nj = F.njobs;
                 const double *r0 = kb->ray + jb;
                 ox = PT_LD_NT(1, r0[rk]);
