@@ -1311,11 +1311,20 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
 #ifndef PT_STREAM_NT
 #define PT_STREAM_NT 0
 #endif
+#ifndef PT_L_STRIDE
+#define PT_L_STRIDE 4  // doubles per radiance record (r, g, b and a pad that makes the record one 32-byte sector; 3 = packed, measured: resolve_kernel 11.5 -> 8.7 ms per
+                      // C4 frame, the trace passes +2 ... 4 ms -- two stores per path ending, records across sectors --, profiles/r04_radiance_stride_ab.txt)
+#endif
 #define PT_LD_NT(bit, lv) ((PT_STREAM_NT & (bit)) ? __builtin_nontemporal_load(&(lv)) : (lv))
 #define PT_ST_NT(bit, lv, v) do { if (PT_STREAM_NT & (bit)) __builtin_nontemporal_store((v), &(lv)); else (lv) = (v); } while (0)
 typedef double pt_d4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_radiance(double *L, size_t job, double x, double y, double z) {
-    if (PT_STREAM_NT & 2) {
+    if (PT_L_STRIDE == 3) {
+        double *p = L + 3 * job;
+        p[0] = x;
+        p[1] = y;
+        p[2] = z;
+    } else if (PT_STREAM_NT & 2) {
         const pt_d4v v = {x, y, z, 0.0};
         __builtin_nontemporal_store(v, reinterpret_cast<pt_d4v *>(L) + job);
     } else {
@@ -2758,7 +2767,12 @@ __global__ __launch_bounds__(PT_BLOCK) void resolve_kernel(const ResolveArgs R) 
             const size_t base = (size_t)blk * R.S * 64u + p;
             for (uint32_t s = 0; s < R.S; s++) {  // col = col.add(sample), renderer.go:186, in sample order
                 const size_t j = base + (size_t)s * 64u;
-                if (PT_STREAM_NT & 2) {
+                if (PT_L_STRIDE == 3) {
+                    const double *l = R.L + 3 * j;
+                    cx += l[0];
+                    cy += l[1];
+                    cz += l[2];
+                } else if (PT_STREAM_NT & 2) {
                     const pt_d4v l = __builtin_nontemporal_load(reinterpret_cast<const pt_d4v *>(R.L) + j);
                     cx += l.x;
                     cy += l.y;

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_shade32_kernel(const Walk32Args K
                 }
             }
             if (finished) {
-                reinterpret_cast<double4 *>(B.L)[job] = make_double4(Tx * termx, Ty * termy, Tz * termz, 0.0);
+                ptk::store_radiance(B.L, job, Tx * termx, Ty * termy, Tz * termz);
                 if (STATS) { B.job_seg[job] = j_seg; B.job_draw[job] = j_draw; }
             }
         }
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_exit32_kernel(const Walk32Args K)
             exit_post(lds_mat[exit_mat], ebest, tmax, ox, oy, oz, dx, dy, dz, attx, atty, attz);
             const bool finished = roulette_advance<STATS>(depth, attx, atty, attz, Tx, Ty, Tz, rs, c_draw, j_draw);
             if (finished) {
-                reinterpret_cast<double4 *>(B.L)[job] = make_double4(Tx * 0.0, Ty * 0.0, Tz * 0.0, 0.0);
+                ptk::store_radiance(B.L, job, Tx * 0.0, Ty * 0.0, Tz * 0.0);
                 if (STATS) { B.job_seg[job] = j_seg; B.job_draw[job] = j_draw; }
             } else {
                 go_on = true;

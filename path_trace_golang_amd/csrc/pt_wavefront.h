@@ -202,7 +202,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_init_kernel(const WfArgs A) {
             c_samples++;
             c_draw += nd;
             if (F.max_depth <= 0) {  // rayColorOpt returns black before any scan (renderer.go:287-289)
-                reinterpret_cast<double4 *>(B.L)[i] = make_double4(0.0, 0.0, 0.0, 0.0);
+                ptk::store_radiance(B.L, i, 0.0, 0.0, 0.0);
                 if (STATS) { B.job_seg[i] = 0; B.job_draw[i] = nd; }
             } else {
                 job = i;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_shade_kernel(const WfArgs A) {
                 }
             }
             if (finished) {
-                reinterpret_cast<double4 *>(B.L)[job] = make_double4(Tx * termx, Ty * termy, Tz * termz, 0.0);
+                ptk::store_radiance(B.L, job, Tx * termx, Ty * termy, Tz * termz);
                 if (STATS) { B.job_seg[job] = j_seg; B.job_draw[job] = j_draw; }
             }
         }
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_exit_kernel(const WfArgs A) {
             exit_post(lds_mat[exit_mat], ebest, tmax, ox, oy, oz, dx, dy, dz, attx, atty, attz);
             const bool finished = roulette_advance<STATS>(depth, attx, atty, attz, Tx, Ty, Tz, rs, c_draw, j_draw);
             if (finished) {
-                reinterpret_cast<double4 *>(B.L)[job] = make_double4(Tx * 0.0, Ty * 0.0, Tz * 0.0, 0.0);
+                ptk::store_radiance(B.L, job, Tx * 0.0, Ty * 0.0, Tz * 0.0);
                 if (STATS) { B.job_seg[job] = j_seg; B.job_draw[job] = j_draw; }
             } else {
                 go_on = true;
