@@ -1306,30 +1306,12 @@ __device__ __forceinline__ bool scan_bvh(const DevFrame &F, ObjPtr g_obj, IdxPtr
     return true;
 }
 
-// Streaming data -- primary rays, radiance records, path-state queue entries: written once, read once, gigabytes apart -- can carry the
-// non-temporal hint (PT_STREAM_NT bits: 1 rays, 2 radiance records, 4 queue entries), so that they do not displace what is re-read.
-#ifndef PT_STREAM_NT
-#define PT_STREAM_NT 0
-#endif
-#ifndef PT_L_STRIDE
-#define PT_L_STRIDE 4  // doubles per radiance record (r, g, b and a pad that makes the record one 32-byte sector; 3 = packed, measured: resolve_kernel 11.5 -> 8.7 ms per
-                      // C4 frame, the trace passes +2 ... 4 ms -- two stores per path ending, records across sectors --, profiles/r04_radiance_stride_ab.txt)
-#endif
-#define PT_LD_NT(bit, lv) ((PT_STREAM_NT & (bit)) ? __builtin_nontemporal_load(&(lv)) : (lv))
-#define PT_ST_NT(bit, lv, v) do { if (PT_STREAM_NT & (bit)) __builtin_nontemporal_store((v), &(lv)); else (lv) = (v); } while (0)
-typedef double pt_d4v __attribute__((ext_vector_type(4)));
+// One radiance record: r, g, b and a pad that makes it one whole 32-byte sector per path ending.  (Round 4 measured the alternatives on C4, same box: packed 24-byte
+// records take resolve_kernel from 11.5 to 8.7 ms per frame and cost the trace passes 2 - 4 ms -- two stores per ending, records across sectors --,
+// profiles/r04_radiance_stride_ab.txt; the non-temporal hint on these stores, on the ray planes and on the queue entries -- all written once and read once,
+// gigabytes apart -- stays within the noise, profiles/r04_stream_nt_ab.txt.)
 __device__ __forceinline__ void store_radiance(double *L, size_t job, double x, double y, double z) {
-    if (PT_L_STRIDE == 3) {
-        double *p = L + 3 * job;
-        p[0] = x;
-        p[1] = y;
-        p[2] = z;
-    } else if (PT_STREAM_NT & 2) {
-        const pt_d4v v = {x, y, z, 0.0};
-        __builtin_nontemporal_store(v, reinterpret_cast<pt_d4v *>(L) + job);
-    } else {
-        reinterpret_cast<double4 *>(L)[job] = make_double4(x, y, z, 0.0);
-    }
+    reinterpret_cast<double4 *>(L)[job] = make_double4(x, y, z, 0.0);
 }
 
 // Ray generation pre-pass: one thread per job of the chunk, all lanes busy and neighbouring
@@ -1353,7 +1335,7 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_kernel(const DevFrame F, cons
     const uint32_t x = tx * 32u + (sb & 3u) * 8u + (p & 7u);
     const uint32_t y = ty * 32u + (sb >> 2) * 8u + (p >> 3);
     if (!(x < (uint32_t)F.width && y < (uint32_t)F.height)) {
-        PT_ST_NT(1, ray_ndraw[myjob], 0xffffu);
+        ray_ndraw[myjob] = 0xffffu;
         return;
     }
     uint32_t nd = 0;
@@ -1405,14 +1387,14 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_kernel(const DevFrame F, cons
     }
 #undef RG_DRAW
     const size_t nj = F.njobs;
-    PT_ST_NT(1, ray[myjob], ox);
-    PT_ST_NT(1, ray[nj + myjob], oy);
-    PT_ST_NT(1, ray[2 * nj + myjob], oz);
-    PT_ST_NT(1, ray[3 * nj + myjob], dx);
-    PT_ST_NT(1, ray[4 * nj + myjob], dy);
-    PT_ST_NT(1, ray[5 * nj + myjob], dz);
-    PT_ST_NT(1, ray_rng[myjob], rs);
-    PT_ST_NT(1, ray_ndraw[myjob], (uint16_t)(nd < 0xfffeu ? nd : 0xfffeu));
+    ray[myjob] = ox;
+    ray[nj + myjob] = oy;
+    ray[2 * nj + myjob] = oz;
+    ray[3 * nj + myjob] = dx;
+    ray[4 * nj + myjob] = dy;
+    ray[5 * nj + myjob] = dz;
+    ray_rng[myjob] = rs;
+    ray_ndraw[myjob] = (uint16_t)(nd < 0xfffeu ? nd : 0xfffeu);
 }
 
 // Ray generation for a thin-lens camera (lens_radius > 0).  The lens sample is a rejection loop (randomInUnitSphere,
@@ -1505,7 +1487,7 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_lens_kernel(const DevFrame F,
         if (myjob >= F.njobs) continue;
         const uint32_t nd = s_nd[k][tid];
         if (nd == 0xffffffffu) {
-            PT_ST_NT(1, ray_ndraw[myjob], 0xffffu);
+            ray_ndraw[myjob] = 0xffffu;
             continue;
         }
         const double rx = s_rx[k][tid] * cam.lens_radius;
@@ -1513,14 +1495,14 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_lens_kernel(const DevFrame F,
         const double offx = cam.u[0] * rx + cam.v[0] * ry;
         const double offy = cam.u[1] * rx + cam.v[1] * ry;
         const double offz = cam.u[2] * rx + cam.v[2] * ry;
-        PT_ST_NT(1, ray[myjob], cam.origin[0] + offx);
-        PT_ST_NT(1, ray[nj + myjob], cam.origin[1] + offy);
-        PT_ST_NT(1, ray[2 * nj + myjob], cam.origin[2] + offz);
-        PT_ST_NT(1, ray[3 * nj + myjob], (s_ax[k][tid] - cam.origin[0]) - offx);
-        PT_ST_NT(1, ray[4 * nj + myjob], (s_ay[k][tid] - cam.origin[1]) - offy);
-        PT_ST_NT(1, ray[5 * nj + myjob], (s_az[k][tid] - cam.origin[2]) - offz);
-        PT_ST_NT(1, ray_rng[myjob], s_rs[k][tid]);
-        PT_ST_NT(1, ray_ndraw[myjob], (uint16_t)(nd < 0xfffeu ? nd : 0xfffeu));
+        ray[myjob] = cam.origin[0] + offx;
+        ray[nj + myjob] = cam.origin[1] + offy;
+        ray[2 * nj + myjob] = cam.origin[2] + offz;
+        ray[3 * nj + myjob] = (s_ax[k][tid] - cam.origin[0]) - offx;
+        ray[4 * nj + myjob] = (s_ay[k][tid] - cam.origin[1]) - offy;
+        ray[5 * nj + myjob] = (s_az[k][tid] - cam.origin[2]) - offz;
+        ray_rng[myjob] = s_rs[k][tid];
+        ray_ndraw[myjob] = (uint16_t)(nd < 0xfffeu ? nd : 0xfffeu);
     }
 }
 
@@ -1634,7 +1616,7 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_lens_pool_kernel(const DevFra
         if (myjob >= F.njobs) continue;
         const uint32_t nd = p_nd[k * 64u + lane];
         if (nd == 0xffffu) {
-            PT_ST_NT(1, ray_ndraw[myjob], 0xffffu);
+            ray_ndraw[myjob] = 0xffffu;
             continue;
         }
         const double rx = p_rx[k * 64u + lane] * cam.lens_radius;
@@ -1642,14 +1624,14 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_lens_pool_kernel(const DevFra
         const double offx = cam.u[0] * rx + cam.v[0] * ry;
         const double offy = cam.u[1] * rx + cam.v[1] * ry;
         const double offz = cam.u[2] * rx + cam.v[2] * ry;
-        PT_ST_NT(1, ray[myjob], cam.origin[0] + offx);
-        PT_ST_NT(1, ray[nj + myjob], cam.origin[1] + offy);
-        PT_ST_NT(1, ray[2 * nj + myjob], cam.origin[2] + offz);
-        PT_ST_NT(1, ray[3 * nj + myjob], (ax[k] - cam.origin[0]) - offx);
-        PT_ST_NT(1, ray[4 * nj + myjob], (ay[k] - cam.origin[1]) - offy);
-        PT_ST_NT(1, ray[5 * nj + myjob], (az[k] - cam.origin[2]) - offz);
-        PT_ST_NT(1, ray_rng[myjob], p_rs[k * 64u + lane]);
-        PT_ST_NT(1, ray_ndraw[myjob], (uint16_t)nd);
+        ray[myjob] = cam.origin[0] + offx;
+        ray[nj + myjob] = cam.origin[1] + offy;
+        ray[2 * nj + myjob] = cam.origin[2] + offz;
+        ray[3 * nj + myjob] = (ax[k] - cam.origin[0]) - offx;
+        ray[4 * nj + myjob] = (ay[k] - cam.origin[1]) - offy;
+        ray[5 * nj + myjob] = (az[k] - cam.origin[2]) - offz;
+        ray_rng[myjob] = p_rs[k * 64u + lane];
+        ray_ndraw[myjob] = (uint16_t)nd;
     }
 }
 
@@ -2099,22 +2081,22 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 // (addresses as the scalar base of the wave's claim + rank, see the fresh rays below)
                 const uint32_t rk = rank & 63u;
                 const size_t c0 = cur0;
-                job = PT_LD_NT(4, (cq->job + c0)[rk]);
+                job = (cq->job + c0)[rk];
                 active = job != PT_HOLE;  // a slot some wave of glass_kernel reserved and did not fill
                 if (SPLIT && active) c_contin++;
                 mode = 0;
-                depth = PT_LD_NT(4, (cq->depth + c0)[rk]);
+                depth = (cq->depth + c0)[rk];
                 const double *q0 = cq->d + c0;
-                ox = PT_LD_NT(4, q0[rk]);
-                oy = PT_LD_NT(4, (q0 + qc)[rk]);
-                oz = PT_LD_NT(4, (q0 + 2 * qc)[rk]);
-                dx = PT_LD_NT(4, (q0 + 3 * qc)[rk]);
-                dy = PT_LD_NT(4, (q0 + 4 * qc)[rk]);
-                dz = PT_LD_NT(4, (q0 + 5 * qc)[rk]);
-                Tx = PT_LD_NT(4, (q0 + 6 * qc)[rk]);
-                Ty = PT_LD_NT(4, (q0 + 7 * qc)[rk]);
-                Tz = PT_LD_NT(4, (q0 + 8 * qc)[rk]);
-                rs = PT_LD_NT(4, (cq->rs + c0)[rk]);
+                ox = q0[rk];
+                oy = (q0 + qc)[rk];
+                oz = (q0 + 2 * qc)[rk];
+                dx = (q0 + 3 * qc)[rk];
+                dy = (q0 + 4 * qc)[rk];
+                dz = (q0 + 5 * qc)[rk];
+                Tx = (q0 + 6 * qc)[rk];
+                Ty = (q0 + 7 * qc)[rk];
+                Tz = (q0 + 8 * qc)[rk];
+                rs = (cq->rs + c0)[rk];
                 if (STATS) { j_seg = cq->jseg[item]; j_draw = cq->jdraw[item]; }
             } else if (take) {
                 // the primary ray of this job was generated by raygen_kernel (coherent pre-pass)
@@ -2123,7 +2105,7 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 // addresses as (scalar base of the wave's claim) + rank: no 64-bit vector arithmetic per plane
                 const uint32_t rk = rank & 63u;  // (rank < 64: said so, the offset fits the 32-bit lane offset of a scalar-base load)
                 const int64_t jb = (int64_t)cur0 - (int64_t)n_cont;  // job of rank 0 (below zero while the claim still holds continuations)
-                const uint32_t nd = PT_LD_NT(1, (kb->ray_ndraw + jb)[rk]);
+                const uint32_t nd = (kb->ray_ndraw + jb)[rk];
                 // the ray is fetched before nd is looked at (an out-of-frame job's slots exist too, their content is not used): one
                 // round trip to memory per refill instead of two in a row
                 // (assigned here, not under the test: the compiler would sink the loads back below it)
@@ -2132,13 +2114,13 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                 // the other five waves of the SIMD cover this round trip already, and the prefetch costs a uniform branch and address arithmetic on every refill.)
                 const size_t nj = F.njobs;
                 const double *r0 = kb->ray + jb;
-                ox = PT_LD_NT(1, r0[rk]);
-                oy = PT_LD_NT(1, (r0 + nj)[rk]);
-                oz = PT_LD_NT(1, (r0 + 2 * nj)[rk]);
-                dx = PT_LD_NT(1, (r0 + 3 * nj)[rk]);
-                dy = PT_LD_NT(1, (r0 + 4 * nj)[rk]);
-                dz = PT_LD_NT(1, (r0 + 5 * nj)[rk]);
-                rs = PT_LD_NT(1, (kb->ray_rng + jb)[rk]);
+                ox = r0[rk];
+                oy = (r0 + nj)[rk];
+                oz = (r0 + 2 * nj)[rk];
+                dx = (r0 + 3 * nj)[rk];
+                dy = (r0 + 4 * nj)[rk];
+                dz = (r0 + 5 * nj)[rk];
+                rs = (kb->ray_rng + jb)[rk];
                 if (nd != 0xffffu && F.max_depth <= 0) {
                     // rayColorOpt returns black before any scan (renderer.go:287-289); the camera draws happened
                     c_samples++;
@@ -2406,20 +2388,20 @@ __global__ __launch_bounds__(PT_BLOCK, PROF ? 1
                     // entry `idx` past slot `base` of every plane
                     auto store_entry = [&](size_t base, uint32_t idx) {
                         double *q0 = gq->d + base;
-                        PT_ST_NT(4, q0[idx], ox);
-                        PT_ST_NT(4, (q0 + qc)[idx], oy);
-                        PT_ST_NT(4, (q0 + 2 * qc)[idx], oz);
-                        PT_ST_NT(4, (q0 + 3 * qc)[idx], dx);
-                        PT_ST_NT(4, (q0 + 4 * qc)[idx], dy);
-                        PT_ST_NT(4, (q0 + 5 * qc)[idx], dz);
-                        PT_ST_NT(4, (q0 + 6 * qc)[idx], Tx);
-                        PT_ST_NT(4, (q0 + 7 * qc)[idx], Ty);
-                        PT_ST_NT(4, (q0 + 8 * qc)[idx], Tz);
-                        PT_ST_NT(4, (q0 + 9 * qc)[idx], tmax);
-                        PT_ST_NT(4, (gq->rs + base)[idx], rs);
-                        PT_ST_NT(4, (gq->job + base)[idx], job);
-                        PT_ST_NT(4, (gq->depth + base)[idx], depth);
-                        PT_ST_NT(4, (gq->best + base)[idx], best);
+                        q0[idx] = ox;
+                        (q0 + qc)[idx] = oy;
+                        (q0 + 2 * qc)[idx] = oz;
+                        (q0 + 3 * qc)[idx] = dx;
+                        (q0 + 4 * qc)[idx] = dy;
+                        (q0 + 5 * qc)[idx] = dz;
+                        (q0 + 6 * qc)[idx] = Tx;
+                        (q0 + 7 * qc)[idx] = Ty;
+                        (q0 + 8 * qc)[idx] = Tz;
+                        (q0 + 9 * qc)[idx] = tmax;
+                        (gq->rs + base)[idx] = rs;
+                        (gq->job + base)[idx] = job;
+                        (gq->depth + base)[idx] = depth;
+                        (gq->best + base)[idx] = best;
                         if (STATS) { (gq->jseg + base)[idx] = j_seg; (gq->jdraw + base)[idx] = j_draw; }
                     };
                     // nearly every push fits the wave's window: the addresses are then a scalar base (the window cursor) + the lane's
@@ -2569,14 +2551,14 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
         int depth = 0;
         if (live) {
             const double *q0 = gq->d + i0;
-            ox = PT_LD_NT(4, q0[lane]); oy = PT_LD_NT(4, (q0 + qg)[lane]); oz = PT_LD_NT(4, (q0 + 2 * qg)[lane]);
-            dx = PT_LD_NT(4, (q0 + 3 * qg)[lane]); dy = PT_LD_NT(4, (q0 + 4 * qg)[lane]); dz = PT_LD_NT(4, (q0 + 5 * qg)[lane]);
-            Tx = PT_LD_NT(4, (q0 + 6 * qg)[lane]); Ty = PT_LD_NT(4, (q0 + 7 * qg)[lane]); Tz = PT_LD_NT(4, (q0 + 8 * qg)[lane]);
-            const double tmax = PT_LD_NT(4, (q0 + 9 * qg)[lane]);
-            rs = PT_LD_NT(4, (gq->rs + i0)[lane]);
-            job = PT_LD_NT(4, (gq->job + i0)[lane]);
-            depth = PT_LD_NT(4, (gq->depth + i0)[lane]);
-            const int best = PT_LD_NT(4, (gq->best + i0)[lane]);
+            ox = q0[lane]; oy = (q0 + qg)[lane]; oz = (q0 + 2 * qg)[lane];
+            dx = (q0 + 3 * qg)[lane]; dy = (q0 + 4 * qg)[lane]; dz = (q0 + 5 * qg)[lane];
+            Tx = (q0 + 6 * qg)[lane]; Ty = (q0 + 7 * qg)[lane]; Tz = (q0 + 8 * qg)[lane];
+            const double tmax = (q0 + 9 * qg)[lane];
+            rs = (gq->rs + i0)[lane];
+            job = (gq->job + i0)[lane];
+            depth = (gq->depth + i0)[lane];
+            const int best = (gq->best + i0)[lane];
             if (STATS) { j_seg = (gq->jseg + i0)[lane]; j_draw = (gq->jdraw + i0)[lane]; }
 
             // hit record of the winner
@@ -2680,18 +2662,18 @@ __global__ __launch_bounds__(PT_BLOCK, (WIDE && PT_FLAT_WAVES > 4) ? 4 : PT_FLAT
                 // its addresses are then the window cursor, a scalar, + the lane's rank)
                 auto store_entry = [&](size_t base, uint32_t idx) {
                     double *q0 = cq->d + base;
-                    PT_ST_NT(4, q0[idx], ox);
-                    PT_ST_NT(4, (q0 + qc)[idx], oy);
-                    PT_ST_NT(4, (q0 + 2 * qc)[idx], oz);
-                    PT_ST_NT(4, (q0 + 3 * qc)[idx], dx);
-                    PT_ST_NT(4, (q0 + 4 * qc)[idx], dy);
-                    PT_ST_NT(4, (q0 + 5 * qc)[idx], dz);
-                    PT_ST_NT(4, (q0 + 6 * qc)[idx], Tx);
-                    PT_ST_NT(4, (q0 + 7 * qc)[idx], Ty);
-                    PT_ST_NT(4, (q0 + 8 * qc)[idx], Tz);
-                    PT_ST_NT(4, (cq->rs + base)[idx], rs);
-                    PT_ST_NT(4, (cq->job + base)[idx], job);
-                    PT_ST_NT(4, (cq->depth + base)[idx], depth);
+                    q0[idx] = ox;
+                    (q0 + qc)[idx] = oy;
+                    (q0 + 2 * qc)[idx] = oz;
+                    (q0 + 3 * qc)[idx] = dx;
+                    (q0 + 4 * qc)[idx] = dy;
+                    (q0 + 5 * qc)[idx] = dz;
+                    (q0 + 6 * qc)[idx] = Tx;
+                    (q0 + 7 * qc)[idx] = Ty;
+                    (q0 + 8 * qc)[idx] = Tz;
+                    (cq->rs + base)[idx] = rs;
+                    (cq->job + base)[idx] = job;
+                    (cq->depth + base)[idx] = depth;
                     if (STATS) { (cq->jseg + base)[idx] = j_seg; (cq->jdraw + base)[idx] = j_draw; }
                 };
                 if (np <= room) store_entry(q_cur0, rank & 63u);
@@ -2767,22 +2749,10 @@ __global__ __launch_bounds__(PT_BLOCK) void resolve_kernel(const ResolveArgs R) 
             const size_t base = (size_t)blk * R.S * 64u + p;
             for (uint32_t s = 0; s < R.S; s++) {  // col = col.add(sample), renderer.go:186, in sample order
                 const size_t j = base + (size_t)s * 64u;
-                if (PT_L_STRIDE == 3) {
-                    const double *l = R.L + 3 * j;
-                    cx += l[0];
-                    cy += l[1];
-                    cz += l[2];
-                } else if (PT_STREAM_NT & 2) {
-                    const pt_d4v l = __builtin_nontemporal_load(reinterpret_cast<const pt_d4v *>(R.L) + j);
-                    cx += l.x;
-                    cy += l.y;
-                    cz += l.z;
-                } else {
-                    const double4 l = reinterpret_cast<const double4 *>(R.L)[j];
-                    cx += l.x;
-                    cy += l.y;
-                    cz += l.z;
-                }
+                const double4 l = reinterpret_cast<const double4 *>(R.L)[j];
+                cx += l.x;
+                cy += l.y;
+                cz += l.z;
                 if (R.job_seg) { nseg += R.job_seg[j]; ndraw += R.job_draw[j]; }
             }
             R.acc[slot] = cx;

@@ -76,11 +76,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_PRIMARY_WAVES) void primary_bvh_kernel
 
     for (uint32_t wj = wave0; (size_t)wj * PT_WAVE < nj; wj += nwaves) {  // njobs is a multiple of 64: a wave's jobs all exist
         const uint32_t job = wj * PT_WAVE + lane;
-        const uint32_t nd = PT_LD_NT(1, B.ray_ndraw[job]);
+        const uint32_t nd = B.ray_ndraw[job];
         const bool have = nd != 0xffffu;  // 0xffff: the job's pixel lies outside the frame (edge tile)
-        double ox = PT_LD_NT(1, B.ray[job]), oy = PT_LD_NT(1, B.ray[nj + job]), oz = PT_LD_NT(1, B.ray[2 * nj + job]);
-        double dx = PT_LD_NT(1, B.ray[3 * nj + job]), dy = PT_LD_NT(1, B.ray[4 * nj + job]), dz = PT_LD_NT(1, B.ray[5 * nj + job]);
-        uint64_t rs = PT_LD_NT(1, B.ray_rng[job]);
+        double ox = B.ray[job], oy = B.ray[nj + job], oz = B.ray[2 * nj + job];
+        double dx = B.ray[3 * nj + job], dy = B.ray[4 * nj + job], dz = B.ray[5 * nj + job];
+        uint64_t rs = B.ray_rng[job];
         uint32_t j_seg = 0, j_draw = nd;
         if (have) { c_samples++; c_draw += nd; }
         if (F.max_depth <= 0) {  // rayColorOpt returns black before any scan (renderer.go:287-289); the camera draws happened
@@ -277,18 +277,18 @@ __global__ __launch_bounds__(PT_BLOCK, PT_PRIMARY_WAVES) void primary_bvh_kernel
             if (go_on && slot >= B.cont.cap) {
                 atomicAdd(B.counters + 19, 1ull);  // cannot happen (the queue holds every job plus every window); never write outside it
             } else if (go_on) {
-                PT_ST_NT(4, B.cont.d[slot], ox);
-                PT_ST_NT(4, B.cont.d[qc + slot], oy);
-                PT_ST_NT(4, B.cont.d[2 * qc + slot], oz);
-                PT_ST_NT(4, B.cont.d[3 * qc + slot], dx);
-                PT_ST_NT(4, B.cont.d[4 * qc + slot], dy);
-                PT_ST_NT(4, B.cont.d[5 * qc + slot], dz);
-                PT_ST_NT(4, B.cont.d[6 * qc + slot], Tx);
-                PT_ST_NT(4, B.cont.d[7 * qc + slot], Ty);
-                PT_ST_NT(4, B.cont.d[8 * qc + slot], Tz);
-                PT_ST_NT(4, B.cont.rs[slot], rs);
-                PT_ST_NT(4, B.cont.job[slot], job);
-                PT_ST_NT(4, B.cont.depth[slot], depth);
+                B.cont.d[slot] = ox;
+                B.cont.d[qc + slot] = oy;
+                B.cont.d[2 * qc + slot] = oz;
+                B.cont.d[3 * qc + slot] = dx;
+                B.cont.d[4 * qc + slot] = dy;
+                B.cont.d[5 * qc + slot] = dz;
+                B.cont.d[6 * qc + slot] = Tx;
+                B.cont.d[7 * qc + slot] = Ty;
+                B.cont.d[8 * qc + slot] = Tz;
+                B.cont.rs[slot] = rs;
+                B.cont.job[slot] = job;
+                B.cont.depth[slot] = depth;
                 if (STATS) { B.cont.jseg[slot] = j_seg; B.cont.jdraw[slot] = j_draw; }
                 c_cont++;
             }
